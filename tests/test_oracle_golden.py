@@ -1,0 +1,224 @@
+"""Pin oracle/restate.py (the CPU restatement) against the golden vectors that
+oracle/gen_golden.py produced from the LIVE reference (tests/golden/*.npz)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import restate as R
+
+RTOL = 1e-5  # third-party arithmetic is torch's; see restate.py header
+
+
+def G(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name + ".npz"), allow_pickle=False)
+
+
+def close(a, b, rtol=RTOL, atol=1e-6):
+    a = a.detach().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+def test_rotate(golden_dir):
+    g = G(golden_dir, "g_rotate")
+    x = torch.from_numpy(g["x"])
+    for a in (0, 90, 180, 270):
+        close(R.rotate(x, a), g["r%d" % a], 0, 0)
+    # numerically counter-clockwise: rotate(x,90)[i,j] = x[j, W-1-i]
+    r = R.rotate(x, 90)
+    assert r[0, 0, 1, 2] == x[0, 0, 2, 4 - 1 - 1]
+    for a, inv in ((90, 270), (180, 180), (270, 90)):
+        assert torch.equal(R.rotate(R.rotate(x, a), inv), x)
+
+
+@pytest.mark.parametrize("cin,cout", [(3, 5), (48, 48)])
+def test_shiftconv(golden_dir, cin, cout):
+    g = G(golden_dir, "g_shiftconv_c%d" % cin)
+    w = R.hash_tensor((cout, cin, 3, 3), 11 + cin, -0.3, 0.3)
+    b = R.hash_tensor((cout,), 12 + cin, -0.1, 0.1)
+    x = R.hash_tensor((2, cin, 8, 8), 13 + cin, -1, 1)
+    close(R.conv3x3(x, w, b, True), g["out"], atol=1e-5)
+
+
+def test_pool(golden_dir):
+    g = G(golden_dir, "g_pool")
+    x = R.hash_tensor((2, 3, 8, 8), 21, -1.0, 0.5)
+    close(R.pool2(x, True), g["shifted"], 0, 0)
+    close(R.pool2(x, False), g["plain"], 0, 0)
+    assert (g["shifted"][:, :, 0, :] >= 0).all()  # the literal zero row takes part in the max
+
+
+@pytest.mark.parametrize("tag,cin,cout,bs", [("bs_rgb", 3, 9, True), ("bs_mono", 1, 2, True),
+                                              ("plain_rgb", 3, 3, False), ("sigma", 3, 1, False)])
+def test_net_forward(golden_dir, tag, cin, cout, bs):
+    g = G(golden_dir, "g_net_" + tag)
+    p = R.make_params(cin, cout, bs, seed=3)
+    x = R.hash_tensor((2, cin, 32, 32), 31, 0, 1).requires_grad_(bs)
+    y = R.net_forward(p, x, bs)
+    close(y, g["out"], rtol=1e-4, atol=2e-5)
+    assert list(R.reference_state_dict(p).keys()) == [str(k) for k in g["keys"]]
+    if bs:
+        gin, = torch.autograd.grad(y[0, :, 13, 17].sum(), x)
+        close(gin[0], g["gin"], rtol=1e-3, atol=1e-6)
+        assert float(gin[0, :, 13, 17].abs().max()) == 0.0      # the blind spot
+        assert float(gin[0, :, 12, 17].abs().max()) > 0.0       # ... and only the centre
+
+
+def test_net_forward_64(golden_dir):
+    g = G(golden_dir, "g_net_bs_rgb64")
+    y = R.net_forward(R.make_params(3, 9, True, seed=4), R.hash_tensor((1, 3, 64, 64), 32, 0, 1), True)
+    close(y, g["out"], rtol=1e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize("style,npar", [("gauss25", 25 / 255.0), ("poisson30", 30.0)])
+@pytest.mark.parametrize("mode", ["known", "const", "var"])
+@pytest.mark.parametrize("ch", [1, 3])
+def test_head(golden_dir, style, npar, mode, ch):
+    g = G(golden_dir, "g_head_%s_%s_c%d" % (style, mode, ch))
+    B, H = 2, 8
+    ncomp = ch + ch * (ch + 1) // 2
+    net_out = R.hash_tensor((B, ncomp, H, H), 41 + ch, -0.4, 0.6)
+    net_out[:, :ch] = R.hash_tensor((B, ch, H, H), 42, 0.05, 0.95)
+    net_out = net_out.clone().requires_grad_(True)
+    noisy = R.hash_tensor((B, ch, H, H), 43, 0.0, 1.0)
+    raw = est = None
+    if mode == "var":
+        raw = R.hash_tensor((B, 1, H, H), 44, 1.0, 3.0).requires_grad_(True)
+        est = raw.mean(dim=(2, 3), keepdim=True)
+    if mode == "const":
+        raw = torch.full((1, 1, 1, 1), 1.7, requires_grad=True)
+        est = raw
+    o = R.ssdn_head(net_out, noisy, torch.full((B, 1, 1, 1), npar), style, mode, est)
+    o["loss"].mean().backward()
+    for k in ("loss", "out", "out_mu", "noise_std", "model_std"):
+        close(o[k], g[k], rtol=2e-4, atol=1e-5)
+    close(net_out.grad, g["g_net_out"], rtol=2e-4, atol=1e-6)
+    if raw is not None:
+        close(raw.grad, g["g_raw"], rtol=2e-4, atol=1e-7)
+
+
+def test_mse_and_mask(golden_dir):
+    out = R.hash_tensor((3, 3, 16, 16), 51, 0, 1).requires_grad_(True)
+    tgt = R.hash_tensor((3, 3, 16, 16), 52, 0, 1)
+    g = G(golden_dir, "g_mse")
+    l = R.mse_loss(out, tgt)
+    l.mean().backward()
+    close(l, g["loss"])
+    close(out.grad, g["g_out"], atol=1e-9)
+    g = G(golden_dir, "g_maskmse")
+    out = R.hash_tensor((3, 3, 16, 16), 51, 0, 1).requires_grad_(True)
+    coords = torch.from_numpy(g["coords"])
+    assert torch.equal(coords, R.hash_tensor((3, 64, 2), 53, 0, 16).long())
+    l = R.mask_mse_loss(coords, out, tgt)
+    l.mean().backward()
+    close(l, g["loss"])
+    close(out.grad, g["g_out"], atol=1e-9)
+
+
+def test_lr_ramp(golden_dir):
+    g = G(golden_dir, "g_lr")
+    for i, lr in zip(g["iters"], g["lr"]):
+        assert R.trainer_lr(int(i), 2000000) == pytest.approx(float(lr), rel=1e-12, abs=0)
+    assert R.trainer_lr(0, 2000000) == 0.0
+    assert R.trainer_lr(1000000, 2000000) == 3e-4
+
+
+def test_psnr(golden_dir):
+    a = R.hash_tensor((3, 3, 16, 16), 71, 0, 1)
+    b = torch.clamp(a + R.hash_tensor((3, 3, 16, 16), 72, -0.1, 0.1), 0, 1)
+    close(R.psnr(a, b), G(golden_dir, "g_psnr")["psnr"])
+
+
+TRAIN_CASES = [("ssdn_known_rgb", "ssdn", "gauss25", "known", 3), ("ssdn_var_rgb", "ssdn", "gauss25", "var", 3),
+               ("ssdn_const_poisson_rgb", "ssdn", "poisson30", "const", 3), ("ssdn_known_mono", "ssdn", "gauss25", "known", 1),
+               ("n2c_mono", "n2c", "gauss25", "known", 1), ("n2v_rgb", "n2v", "gauss25", "known", 3)]
+
+
+def train_inputs(alg, style, ch, P=32, Bn=2):
+    clean = R.hash_tensor((Bn, ch, P, P), 61, 0, 1)
+    npar = 25 / 255.0 if style.startswith("gauss") else 30.0
+    noisy = torch.clamp(clean + (R.hash_tensor((Bn, ch, P, P), 62, -1, 1)) * 0.17, 0, 1)
+    ref = clean if alg != "n2v" else torch.clamp(clean + R.hash_tensor((Bn, ch, P, P), 63, -1, 1) * 0.17, 0, 1)
+    coords = R.hash_tensor((Bn, 16, 2), 64, 0, P).long()
+    return clean, noisy, ref, coords, torch.full((Bn, 1, 1, 1), npar)
+
+
+def param_name_map(names):
+    """reference parameter name -> (which net, restate key)."""
+    out = {}
+    for n in names:
+        n = str(n)
+        if n.startswith("l_params"):
+            out[n] = ("est", None)
+            continue
+        net = "sigma" if "sigma_estimation_model" in n else "main"
+        key = n.split(".module.")[1]
+        key = key.replace("output_conv", "output_block.4")
+        out[n] = (net, key)
+    return out
+
+
+@pytest.mark.parametrize("tag,alg,style,mode,ch", TRAIN_CASES)
+def test_train_trajectory(golden_dir, tag, alg, style, mode, ch):
+    """G6/G7: parameter gradients after one backward and three Adam steps of the reference's
+    Denoiser + torch.optim.Adam(betas=(0.9,0.99)) + swapped-fraction LR ramp."""
+    g = G(golden_dir, "g_train_" + tag)
+    bs = alg == "ssdn"
+    cout = ch + ch * (ch + 1) // 2 if alg == "ssdn" else ch
+    sp = R.make_params(ch, 1, False, seed=6) if mode == "var" and alg == "ssdn" else None
+    tr = R.CpuTrainer(alg, ch, style, mode, params=R.make_params(ch, cout, bs, seed=5), sigma_params=sp)
+    clean, noisy, ref, coords, npar = train_inputs(alg, style, ch)
+    nm = param_name_map(g["names"])
+
+    def tensor_of(name):
+        net, key = nm[name]
+        return tr.est if net == "est" else (tr.ps if net == "sigma" else tr.p)[key]
+
+    for it in range(3):
+        lr = R.trainer_lr((it + 1) * 40, 1000)
+        assert lr == pytest.approx(float(g["lrs"][it]), rel=1e-12)
+        r = tr.step(lr, noisy, ref, npar, coords)
+        close(r["loss"], g["loss_it%d" % it], rtol=5e-4, atol=1e-6)
+        if it == 0:
+            close(r["out"], g["out0"], rtol=1e-3, atol=2e-5)
+    for name in nm:
+        t = tensor_of(name).detach().reshape(-1)
+        assert float(t.double().sum()) == pytest.approx(float(g["sum/" + name]), rel=2e-4, abs=2e-4)
+        close(t[:8], g["head/" + name], rtol=2e-3, atol=2e-6)
+
+
+@pytest.mark.parametrize("tag,alg,style,mode,ch", TRAIN_CASES[:4])
+def test_param_grads(golden_dir, tag, alg, style, mode, ch):
+    g = G(golden_dir, "g_train_" + tag)
+    cout = ch + ch * (ch + 1) // 2
+    sp = R.make_params(ch, 1, False, seed=6) if mode == "var" else None
+    tr = R.CpuTrainer(alg, ch, style, mode, params=R.make_params(ch, cout, True, seed=5), sigma_params=sp)
+    clean, noisy, ref, coords, npar = train_inputs(alg, style, ch)
+    r = tr.forward(noisy, ref, npar, coords)
+    r["loss"].mean().backward()
+    nm = param_name_map(g["names"])
+    for name, (net, key) in nm.items():
+        t = tr.est if net == "est" else (tr.ps if net == "sigma" else tr.p)[key]
+        gn = float(t.grad.double().norm())
+        assert gn == pytest.approx(float(g["gnorm/" + name]), rel=2e-3, abs=1e-7), name
+        close(t.grad.reshape(-1)[:16], g["ghead/" + name], rtol=5e-3, atol=1e-6 + 1e-4 * gn)
+
+
+def test_checkpoint_contract(golden_dir):
+    ck = json.load(open(os.path.join(golden_dir, "g_ckpt_contract.json")))
+    k = ck["ssdn_known"]
+    assert len(k["keys"]) == 85 and k["keys"][-1] == "cfg"
+    assert k["config_name"] == "ssdn-gauss25-sigma_known"
+    assert "ssdn.params.ConfigValue" in k["globals"]
+    assert any(x.startswith("l_params.estimated_sigma") for x in ck["ssdn_const"]["keys"])
+
+
+def test_init_statistics():
+    """H8: make_params has the reference's init variance (noise_network.py:175-184)."""
+    p = R.make_params(3, 9, True, seed=0)
+    w = p["decode_block_1.2.weight"]
+    assert float(w.std()) == pytest.approx((2 / 1.01 / (96 * 9)) ** 0.5, rel=0.02)
+    w = p["output_block.4.weight"]
+    assert float(w.std()) == pytest.approx((1 / 96) ** 0.5, rel=0.06)
