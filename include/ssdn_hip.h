@@ -1,0 +1,323 @@
+/*
+ * ssdn_hip.h -- C-ABI of libssdn_hip.so: the MI355X (gfx950 / CDNA4) hot path of the `ssdn`
+ * blind-spot denoising trainer.
+ *
+ * The reference (COMP6248-Reproducability-Challenge/selfsupervised-denoising) is pure PyTorch and has
+ * NO FFI for this path: every "kernel" below replaces an ATen/cuDNN op the
+ * reference launches implicitly through torch.nn.  Each entry point cites the reference code it
+ * replaces.  The boundary carries plain pointers and sizes only -- no torch types.  The host side
+ * (Python, like the reference) keeps the reference's module API (NoiseNetwork / Denoiser) and lowers
+ * one forward / training step to a flat list of `ssdn_op` records executed by ssdn_run_ops().
+ *
+ * Conventions
+ *   - all device pointers are caller-owned (the Python host allocates them with torch on the
+ *     current device); the library allocates nothing and keeps no state besides the last error.
+ *   - activation tensors: NHWC, fp16, `cs` = elements per pixel (channel stride), `co` = channel offset
+ *     of this view inside the pixel, so concatenations / channel slices are views, never copies.
+ *   - every function returns 0 on success; on failure a negative code and ssdn_last_error() gives text.
+ *     No C++ exception crosses the boundary.
+ *   - `stream` is a hipStream_t (NULL = the default stream); all work is enqueued asynchronously.
+ *   - not thread-safe per stream; one host thread per GPU (one process per GPU).
+ */
+#ifndef SSDN_HIP_H
+#define SSDN_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SSDN_ABI_VERSION 1
+#define SSDN_MAX_TAPS 9
+
+/* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
+typedef struct ssdn_view {
+    void* p;
+    int32_t cs;
+    int32_t co;
+} ssdn_view;
+
+enum ssdn_op_type {
+    SSDN_OP_PACK_INPUT = 1, /* rotate-stack + NCHW f32 -> NHWC f16 */
+    SSDN_OP_CONV = 2,       /* implicit-GEMM MFMA convolution (forward or data-gradient role) */
+    SSDN_OP_POOL_FWD = 3,
+    SSDN_OP_POOL_BWD = 4,
+    SSDN_OP_UPSUM_BWD = 5,
+    SSDN_OP_UNROT_FWD = 6,
+    SSDN_OP_UNROT_BWD = 7,
+    SSDN_OP_WGRAD = 8,
+    SSDN_OP_WREDUCE = 9,
+    SSDN_OP_WPACK = 10,
+    SSDN_OP_GRAD_PACK = 11,
+    SSDN_OP_HEAD_SSDN = 12,
+    SSDN_OP_HEAD_FINAL = 13,
+    SSDN_OP_SPATIAL_MEAN = 14,
+    SSDN_OP_MSE = 15,
+    SSDN_OP_MASK_MSE = 16,
+    SSDN_OP_ADAM = 17,
+    SSDN_OP_SQERR = 18,
+    SSDN_OP_ZERO = 19
+};
+
+/* One record of the op list.  `args` points at the matching ssdn_*_args struct (host memory). */
+typedef struct ssdn_op {
+    int32_t type;
+    int32_t _pad;
+    const void* args;
+} ssdn_op;
+
+/* ---- SSDN_OP_PACK_INPUT ----------------------------------------------------------------------
+ * replaces: the 4-rotation batch stacking, noise_network.py:187-189 + utils/data.py:42-67 (flip/transpose/cat),
+ * and the NCHW-f32 -> NHWC-f16 layout change.  dst[r*B+b, i, j, c] = rot_r(src[b,c])[i,j], r=0..R-1,
+ * rot = (0,90,180,270) with rotate(x,90)[i,j] = x[j, W-1-i]; channels c >= C are written as zero. */
+typedef struct ssdn_pack_input_args {
+    const float* src; /* [B,C,H,W] f32 */
+    ssdn_view dst;    /* [R*B,H,W,cs] f16 */
+    int32_t B, C, H, W;
+    int32_t R;        /* 4 (blind-spot) or 1 */
+    int32_t cpad;     /* channels written (>= C, zero padded) */
+} ssdn_pack_input_args;
+
+/* ---- SSDN_OP_CONV ------------------------------------------------------------------------------
+ * replaces: ShiftConv2d / nn.Conv2d (+bias) + LeakyReLU(0.1) + nn.Upsample(nearest) + torch.cat
+ * (noise_network.py:58,70-156,200-210,241-260) in the forward role, and autograd's conv data-gradient in the
+ * backward role.  Computes, for every output pixel (n,y,x) and m < M:
+ *     v = bias[m] + sum_{t<ntaps} sum_{k<Ktot} Wp[t][m][k] * IN(n, y+dy[t], x+dx[t], k)
+ *     if act:  v = v > 0 ? v : 0.1 v
+ *     if add:  v += add(n,y,x,m)
+ *     if mask: v *= (mask(n,y,x,m) > 0 ? 1 : 0.1)             (LeakyReLU' of a saved activation)
+ * IN is the virtual channel-concatenation [src0 (c0 ch), src1 (c1 ch)], zero outside [0,H)x[0,W);
+ * src0 is read at (y>>1, x>>1) when up0 (nearest 2x upsample folded into the load).
+ * Wp is fp16 [ntaps][Mpad][Ktot] (packed by SSDN_OP_WPACK), Ktot = c0+c1 (multiple of 16), Mpad multiple of 32.
+ * Output: dst (fp16 NHWC view) or, when dst32 != NULL, fp32 NCHW planar [N][M][H][W] (net_out). */
+typedef struct ssdn_conv_args {
+    ssdn_view src0;
+    ssdn_view src1;
+    int32_t c0, c1, up0;
+    int32_t N, H, W;
+    int32_t ntaps;
+    int32_t dy[SSDN_MAX_TAPS];
+    int32_t dx[SSDN_MAX_TAPS];
+    const void* w; /* fp16 [ntaps][Mpad][Ktot] */
+    int32_t M, Mpad, Ktot;
+    const float* bias; /* [M] or NULL */
+    int32_t act;
+    ssdn_view mask; /* p == NULL: none */
+    ssdn_view add;  /* p == NULL: none */
+    ssdn_view dst;
+    float* dst32;
+    /* tiling chosen by the host (see ssdn/hip/graph.py): tile = 2^ltn images x 2^lth rows x 2^ltw cols = 256 px */
+    int32_t ltw, lth, ltn;
+    int32_t kc; /* channel chunk staged in LDS at a time (multiple of 16, divides Ktot) */
+} ssdn_conv_args;
+
+/* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
+ * replaces: Shift2d((1,0)) + nn.MaxPool2d(2) (noise_network.py:64-67, models/utility.py:37-53) and its autograd
+ * backward fused with the LeakyReLU backward of the producing conv.
+ * shifted: window rows {2i-1, 2i}, row -1 is a literal 0 that takes part in the max; else rows {2i, 2i+1}.
+ * BWD: dz(n,y,x,c) = (first position in window scan order whose value equals the pooled max is (y,x))
+ *                    ? dpool(n,i,j,c) * (act > 0 ? 1 : 0.1) : 0;  if the zero pad row wins the gradient is dropped. */
+typedef struct ssdn_pool_args {
+    ssdn_view act;    /* [N,H,W,C] full-res post-activation */
+    ssdn_view pooled; /* [N,H/2,W/2,C]  (FWD: output, BWD: input) */
+    ssdn_view dpool;  /* BWD only */
+    ssdn_view dz;     /* BWD only: [N,H,W,C] */
+    int32_t N, H, W, C;
+    int32_t shifted;
+} ssdn_pool_args;
+
+/* ---- SSDN_OP_UPSUM_BWD ----------------------------------------------------------------------
+ * replaces: autograd backward of nn.Upsample(nearest, 2x) + LeakyReLU backward of the producer.
+ * dst(n,i,j,c) = (sum_{a,b<2} src(n,2i+a,2j+b,c)) * (mask(n,i,j,c) > 0 ? 1 : 0.1); dims are those of dst. */
+typedef struct ssdn_upsum_args {
+    ssdn_view src;  /* [N,2H,2W,..] */
+    ssdn_view mask; /* [N,H,W,..] */
+    ssdn_view dst;  /* [N,H,W,..] */
+    int32_t N, H, W, C;
+} ssdn_upsum_args;
+
+/* ---- SSDN_OP_UNROT_FWD / SSDN_OP_UNROT_BWD --------------------------------------------------
+ * replaces: final Shift2d((1,0)), chunk(4), un-rotate (0,270,180,90), cat(dim=1) (noise_network.py:213-222).
+ * FWD: dst[b,i,j,r*C+c] = S_r(src)[..], S_r[y,x] = y>=1 ? src[r*B+b, y-1, x] : 0, rotated back by (0,270,180,90).
+ * BWD: the adjoint, times LeakyReLU'(act) of the tensor that was un-rotated. */
+typedef struct ssdn_unrot_args {
+    ssdn_view src;  /* FWD: [4B,P,P,C] ; BWD: [B,P,P,4C] (gradient) */
+    ssdn_view dst;  /* FWD: [B,P,P,4C] ; BWD: [4B,P,P,C] */
+    ssdn_view mask; /* BWD only: [4B,P,P,C] saved activation */
+    int32_t B, P, C;
+} ssdn_unrot_args;
+
+/* ---- SSDN_OP_WGRAD --------------------------------------------------------------------------
+ * replaces: autograd's conv weight/bias gradient.  Every workgroup s < nslabs reduces its share of pixels into
+ *   slab[s][t][m][k] = sum_pixels dz(n,y,x,m) * IN(n, y+dy[t], x+dx[t], k)      (fp32, [nslabs][ntaps][Mpad][Kpad])
+ *   bslab[s][m]      = sum_pixels dz(n,y,x,m)
+ * IN as in SSDN_OP_CONV.  Deterministic: fixed pixel->workgroup assignment, SSDN_OP_WREDUCE sums slabs in order. */
+typedef struct ssdn_wgrad_args {
+    ssdn_view dz; /* [N,H,W,..] gradient w.r.t. the conv's pre-activation output, M channels */
+    ssdn_view src0;
+    ssdn_view src1;
+    int32_t c0, c1, up0;
+    int32_t N, H, W;
+    int32_t ntaps;
+    int32_t dy[SSDN_MAX_TAPS];
+    int32_t dx[SSDN_MAX_TAPS];
+    int32_t M, Mpad, Ktot, Kpad;
+    float* slab;
+    float* bslab;
+    int32_t nslabs;
+    int32_t ltw, lth, ltn; /* pixel tile per iteration: 2^ltn x 2^lth x 2^ltw */
+} ssdn_wgrad_args;
+
+/* ---- SSDN_OP_WREDUCE ------------------------------------------------------------------------
+ * gw[m][cin][ky][kx] (fp32 OIHW, the checkpoint layout) = inv_scale * sum_s slab[s][t][m][k(cin)],
+ * gb[m] = inv_scale * sum_s bslab[s][m];  k(cin) = cin (cin < c0) else c0 + (cin - c0) i.e. padding removed:
+ * real input channels are [0,c0) and [c0, c0+c1_real).  inv_scale is read from device memory (loss-scale word). */
+typedef struct ssdn_wreduce_args {
+    const float* slab;
+    const float* bslab;
+    int32_t nslabs, ntaps, M, Mpad, Kpad;
+    int32_t cin;      /* real input channels covered by this slab (k < cin are real, the rest is padding) */
+    int32_t cin_full; /* input channels of the whole weight tensor (row length of gw) */
+    int32_t m_off, c_off; /* this slab is the block gw[m_off.., c_off..] (the 1x1 head layers are computed in blocks) */
+    float* gw;
+    float* gb; /* may be NULL (bias gradient is produced by one block column only) */
+    const float* inv_scale; /* device scalar, may be NULL (=1) */
+} ssdn_wreduce_args;
+
+/* ---- SSDN_OP_WPACK --------------------------------------------------------------------------
+ * fp32 OIHW master weights -> the two fp16 shadows the MFMA kernels read:
+ *   wf[t][m][k]  (forward role)  = W[m][cin(k)][t]  for m < M, k real; 0 in the padding   [ntaps][Mpad_f][Ktot]
+ *   wd[t][c][m]  (dgrad role)    = W[m][cin(c)][t]                                        [ntaps][Mpad_d][Kd]
+ * k -> cin: k < c0 ? k : (k - c0 < c1_real ? c0 + k - c0 : padding). */
+typedef struct ssdn_wpack_args {
+    const float* w; /* [M][cin][ntaps] */
+    void* wf;
+    void* wd; /* may be NULL (first layer needs no data gradient) */
+    int32_t M, cin, ntaps;
+    int32_t c0, c1_real;
+    int32_t Mpad_f, Ktot; /* forward shadow dims */
+    int32_t Mpad_d, Kd;   /* dgrad shadow dims: Mpad_d >= Ktot, Kd >= M (multiple of 16) */
+} ssdn_wpack_args;
+
+/* ---- SSDN_OP_GRAD_PACK ----------------------------------------------------------------------
+ * fp32 NCHW gradient w.r.t. net_out -> fp16 NHWC [N,H,W,cpad] times a power-of-two loss scale chosen from the
+ * running max |g| (gmax, written by the loss kernels with atomicMax on the float bits) so that fp16 neither
+ * overflows nor underflows further down the backward pass; writes scale_out[0] = scale, scale_out[1] = 1/scale. */
+typedef struct ssdn_grad_pack_args {
+    const float* g; /* [N,C,H,W] */
+    ssdn_view dst;
+    int32_t N, C, H, W, cpad;
+    const uint32_t* gmax; /* float bits of max |g| */
+    float* scale_out;     /* [2] */
+} ssdn_grad_pack_args;
+
+/* ---- SSDN_OP_HEAD_SSDN / SSDN_OP_HEAD_FINAL -------------------------------------------------
+ * replaces: Denoiser._ssdn_pipeline (denoiser.py:218-397) and its autograd backward:
+ * per-pixel Gaussian posterior algebra in closed form (3x3 SPD inverse/det by adjugate), fp32.
+ *   style: 0 gauss, 1 poisson.   mode: 0 known, 1 const (one learnable scalar), 2 var (sigma-net, one value / sample)
+ *   noise_param[b]: sigma (gauss) or lambda (poisson) for mode known.   est_raw: [1] (const) or [B] (var), pre-softplus.
+ * Outputs (any may be NULL): mu / pme [B,C,H,W], model_std [B,H,W], noise_std [B] (gauss) or [B,H,W] (poisson),
+ *   g_net_out [B,Cout,H,W] = d mean(LOSS) / d net_out, partial[b][chunk][2] = {sum loss, sum dloss/dest_raw} per workgroup,
+ *   gmax = atomicMax of |g| float bits.
+ * HEAD_FINAL sums the partials in fixed order: loss[b] = mean over pixels; g_est (const: [1], var: [B]);
+ *   for var also fills g_sigma_out [B,1,H,W] with g_est[b]/(H*W) (gradient of the spatial mean) and folds it into gmax2. */
+typedef struct ssdn_head_args {
+    const float* net_out; /* [B,Cout,H,W] */
+    const float* noisy;   /* [B,C,H,W] */
+    const float* noise_param;
+    const float* est_raw;
+    int32_t B, C, H, W;
+    int32_t style, mode;
+    int32_t want_grad;
+    float* mu;
+    float* pme;
+    float* model_std;
+    float* noise_std;
+    float* g_net_out;
+    float* partial;
+    int32_t nchunks;
+    uint32_t* gmax;
+} ssdn_head_args;
+
+typedef struct ssdn_head_final_args {
+    const float* partial;
+    int32_t B, nchunks, H, W;
+    int32_t mode;
+    float* loss;        /* [B] */
+    float* g_est;       /* [1] or [B] */
+    float* g_sigma_out; /* var: [B,1,H,W] */
+    uint32_t* gmax2;    /* var: max |g_sigma_out| bits */
+} ssdn_head_final_args;
+
+/* mean over H,W of a [B,1,H,W] fp32 map (denoiser.py:264) */
+typedef struct ssdn_spatial_mean_args {
+    const float* src;
+    float* dst;
+    int32_t B, HW;
+} ssdn_spatial_mean_args;
+
+/* ---- SSDN_OP_MSE / SSDN_OP_MASK_MSE ---------------------------------------------------------
+ * replaces: Denoiser._mse_pipeline (denoiser.py:153-154) / loss_mask_mse (utils/n2v_loss.py:6-17, quirk kept:
+ * coordinates of batch element 0 are used for every element, squared errors summed over coordinates, mean over C).
+ * loss[b]; g = d mean_b(loss) / d out (fp32 NCHW); gmax as above. */
+typedef struct ssdn_mse_args {
+    const float* out; /* [B,C,H,W] */
+    const float* ref;
+    const int64_t* coords; /* MASK_MSE: [ncoords][2] (row, col) of batch element 0 */
+    int32_t ncoords;
+    int32_t B, C, H, W;
+    float* loss;
+    float* g;
+    uint32_t* gmax;
+} ssdn_mse_args;
+
+/* ---- SSDN_OP_ADAM ---------------------------------------------------------------------------
+ * replaces: torch.optim.Adam.step over all parameters (train.py:100-107,202): one fused pass over the flat fp32
+ * master buffer.  p -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps), bc = 1 - beta^step (host computes bc1, bc2). */
+typedef struct ssdn_adam_args {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    int64_t n;
+    float lr, b1, b2, eps, bc1, bc2;
+    float gscale; /* multiplies g first (1/world_size for data parallel) */
+} ssdn_adam_args;
+
+/* per-sample sum of squared error (PSNR numerator, utils/data.py:94-105): dst[b] = mean_{chw} (a-b)^2 */
+typedef struct ssdn_sqerr_args {
+    const float* a;
+    const float* b;
+    float* dst;
+    int32_t B, n; /* n = C*H*W */
+} ssdn_sqerr_args;
+
+typedef struct ssdn_zero_args {
+    void* p;
+    int64_t bytes;
+} ssdn_zero_args;
+
+/* Execute `n` ops in order on `stream`.  Returns 0 or a negative error (ssdn_last_error()). */
+int ssdn_run_ops(const ssdn_op* ops, int n, void* stream);
+
+/* Bytes of dynamic LDS a conv op will request (host-side check of a tiling), or < 0 if the tiling is invalid. */
+int ssdn_conv_lds_bytes(const ssdn_conv_args* a);
+int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a);
+
+/* sizeof() of the args struct for an op type (0: ssdn_op itself); lets a binding verify its struct mirrors */
+int ssdn_struct_size(int op_type);
+int ssdn_abi_version(void);
+const char* ssdn_last_error(void);
+/* number of compute units of the current device (used to size persistent grids) */
+int ssdn_device_cus(void);
+
+/* Hardware probes used by the test-suite (tests/test_hip_probe.py): raw lane mapping of
+ * v_mfma_f32_32x32x16_f16 and ds_read_b64_tr_b16 on this device.  out: device buffers. */
+int ssdn_probe_mfma(const void* a_frag, const void* b_frag, float* d_out, void* stream);
+int ssdn_probe_tr16(const void* lds_image, int image_bytes, const int32_t* lane_addr, void* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SSDN_HIP_H */

@@ -1,0 +1,146 @@
+// api.hip -- the extern "C" surface of libssdn_hip.so (see include/ssdn_hip.h): op-list executor, error text,
+// device query and two hardware probes used by the GPU test-suite.
+#include "common.h"
+#include <cstdarg>
+#include <cstdio>
+
+static thread_local char g_err[512] = "";
+
+int ssdn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return -1;
+}
+
+__global__ void k_zero(uint4* p, long long n16) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i < n16; i += (long long)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
+}
+
+extern "C" {
+
+int ssdn_abi_version(void) { return SSDN_ABI_VERSION; }
+const char* ssdn_last_error(void) { return g_err; }
+
+int ssdn_device_cus(void) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return ssdn_set_error("hipGetDevice failed");
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+        return ssdn_set_error("hipDeviceGetAttribute failed");
+    return cus;
+}
+
+/* sizeof() of the args struct of an op type -- lets the Python binding verify its ctypes mirrors (tests/test_abi.py) */
+int ssdn_struct_size(int op_type) {
+    switch (op_type) {
+        case 0: return (int)sizeof(ssdn_op);
+        case SSDN_OP_PACK_INPUT: return (int)sizeof(ssdn_pack_input_args);
+        case SSDN_OP_CONV: return (int)sizeof(ssdn_conv_args);
+        case SSDN_OP_POOL_FWD: case SSDN_OP_POOL_BWD: return (int)sizeof(ssdn_pool_args);
+        case SSDN_OP_UPSUM_BWD: return (int)sizeof(ssdn_upsum_args);
+        case SSDN_OP_UNROT_FWD: case SSDN_OP_UNROT_BWD: return (int)sizeof(ssdn_unrot_args);
+        case SSDN_OP_WGRAD: return (int)sizeof(ssdn_wgrad_args);
+        case SSDN_OP_WREDUCE: return (int)sizeof(ssdn_wreduce_args);
+        case SSDN_OP_WPACK: return (int)sizeof(ssdn_wpack_args);
+        case SSDN_OP_GRAD_PACK: return (int)sizeof(ssdn_grad_pack_args);
+        case SSDN_OP_HEAD_SSDN: return (int)sizeof(ssdn_head_args);
+        case SSDN_OP_HEAD_FINAL: return (int)sizeof(ssdn_head_final_args);
+        case SSDN_OP_SPATIAL_MEAN: return (int)sizeof(ssdn_spatial_mean_args);
+        case SSDN_OP_MSE: case SSDN_OP_MASK_MSE: return (int)sizeof(ssdn_mse_args);
+        case SSDN_OP_ADAM: return (int)sizeof(ssdn_adam_args);
+        case SSDN_OP_SQERR: return (int)sizeof(ssdn_sqerr_args);
+        case SSDN_OP_ZERO: return (int)sizeof(ssdn_zero_args);
+        default: return -1;
+    }
+}
+
+int ssdn_conv_lds_bytes(const ssdn_conv_args* a) { return conv_lds_bytes(a); }
+int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a) { return wgrad_lds_bytes(a); }
+
+int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
+    hipStream_t s = (hipStream_t)stream;
+    for (int i = 0; i < n; ++i) {
+        const void* p = ops[i].args;
+        int rc = 0;
+        if (!p) return ssdn_set_error("op %d: null args", i);
+        switch (ops[i].type) {
+            case SSDN_OP_PACK_INPUT: rc = launch_pack_input((const ssdn_pack_input_args*)p, s); break;
+            case SSDN_OP_CONV: rc = launch_conv((const ssdn_conv_args*)p, s); break;
+            case SSDN_OP_POOL_FWD: rc = launch_pool_fwd((const ssdn_pool_args*)p, s); break;
+            case SSDN_OP_POOL_BWD: rc = launch_pool_bwd((const ssdn_pool_args*)p, s); break;
+            case SSDN_OP_UPSUM_BWD: rc = launch_upsum_bwd((const ssdn_upsum_args*)p, s); break;
+            case SSDN_OP_UNROT_FWD: rc = launch_unrot_fwd((const ssdn_unrot_args*)p, s); break;
+            case SSDN_OP_UNROT_BWD: rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
+            case SSDN_OP_WGRAD: rc = launch_wgrad((const ssdn_wgrad_args*)p, s); break;
+            case SSDN_OP_WREDUCE: rc = launch_wreduce((const ssdn_wreduce_args*)p, s); break;
+            case SSDN_OP_WPACK: rc = launch_wpack((const ssdn_wpack_args*)p, s); break;
+            case SSDN_OP_GRAD_PACK: rc = launch_grad_pack((const ssdn_grad_pack_args*)p, s); break;
+            case SSDN_OP_HEAD_SSDN: rc = launch_head((const ssdn_head_args*)p, s); break;
+            case SSDN_OP_HEAD_FINAL: rc = launch_head_final((const ssdn_head_final_args*)p, s); break;
+            case SSDN_OP_SPATIAL_MEAN: rc = launch_spatial_mean((const ssdn_spatial_mean_args*)p, s); break;
+            case SSDN_OP_MSE: rc = launch_mse((const ssdn_mse_args*)p, 0, s); break;
+            case SSDN_OP_MASK_MSE: rc = launch_mse((const ssdn_mse_args*)p, 1, s); break;
+            case SSDN_OP_ADAM: rc = launch_adam((const ssdn_adam_args*)p, s); break;
+            case SSDN_OP_SQERR: rc = launch_sqerr((const ssdn_sqerr_args*)p, s); break;
+            case SSDN_OP_ZERO: {
+                const ssdn_zero_args* z = (const ssdn_zero_args*)p;
+                if (z->bytes & 15) return ssdn_set_error("op %d: zero size must be a multiple of 16", i);
+                long long n16 = z->bytes / 16;
+                int g = (int)((n16 + 255) / 256);
+                if (g > 2048) g = 2048;
+                if (g > 0) hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, s, (uint4*)z->p, n16);
+                break;
+            }
+            default: return ssdn_set_error("op %d: unknown type %d", i, ops[i].type);
+        }
+        if (rc) {
+            char tmp[400];
+            snprintf(tmp, sizeof(tmp), "%s", g_err);
+            return ssdn_set_error("op %d (type %d): %s", i, ops[i].type, tmp);
+        }
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return ssdn_set_error("launch error: %s", hipGetErrorString(e));
+    return 0;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------
+// hardware probes (test infrastructure on the device side; they pin the lane maps the MFMA kernels rely on)
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_probe_mfma(const half8* a, const half8* b, float* d) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[threadIdx.x], b[threadIdx.x], acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) d[threadIdx.x * 16 + r] = acc[r];
+}
+
+typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 p_fp16x4_t;
+typedef __attribute__((address_space(3))) p_fp16x4_t p_lds_fp16x4;
+__global__ void k_probe_tr16(const uint4* image, int n16, const int* lane_addr, half4* out) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int i = threadIdx.x; i < n16; i += blockDim.x) reinterpret_cast<uint4*>(smem)[i] = image[i];
+    __syncthreads();
+    p_fp16x4_t r = __builtin_amdgcn_ds_read_tr16_b64_v4f16((p_lds_fp16x4*)(smem + lane_addr[threadIdx.x]));
+    out[threadIdx.x] = __builtin_bit_cast(half4, r);
+}
+
+extern "C" {
+int ssdn_probe_mfma(const void* a_frag, const void* b_frag, float* d_out, void* stream) {
+    hipLaunchKernelGGL(k_probe_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, (const half8*)a_frag, (const half8*)b_frag, d_out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ssdn_set_error("probe_mfma: %s", hipGetErrorString(e));
+}
+int ssdn_probe_tr16(const void* lds_image, int image_bytes, const int32_t* lane_addr, void* out, void* stream) {
+    if (image_bytes & 15 || image_bytes > 64 * 1024) return ssdn_set_error("probe_tr16: bad image size");
+    hipLaunchKernelGGL(k_probe_tr16, dim3(1), dim3(64), image_bytes, (hipStream_t)stream, (const uint4*)lds_image,
+                       image_bytes / 16, lane_addr, (half4*)out);
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? 0 : ssdn_set_error("probe_tr16: %s", hipGetErrorString(e));
+}
+}

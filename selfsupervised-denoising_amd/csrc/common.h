@@ -1,0 +1,58 @@
+// common.h -- shared device helpers for the gfx950 kernels of libssdn_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/ssdn_hip.h"
+
+typedef _Float16 h16;
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LRELU_SLOPE 0.1f
+
+// error plumbing (api.hip)
+int ssdn_set_error(const char* fmt, ...);
+#define SSDN_CHECK_HIP(expr)                                                                 \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) return ssdn_set_error("%s failed: %s", #expr, hipGetErrorString(_e)); \
+    } while (0)
+
+static __device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : LRELU_SLOPE * v; }
+static __device__ __forceinline__ float lrelu_grad(float act) { return act > 0.f ? 1.f : LRELU_SLOPE; }
+
+static __device__ __forceinline__ half8 ld_h8(const h16* p) { return *reinterpret_cast<const half8*>(p); }
+static __device__ __forceinline__ void st_h8(h16* p, half8 v) { *reinterpret_cast<half8*>(p) = v; }
+static __device__ __forceinline__ half4 ld_h4(const h16* p) { return *reinterpret_cast<const half4*>(p); }
+static __device__ __forceinline__ void st_h4(h16* p, half4 v) { *reinterpret_cast<half4*>(p) = v; }
+
+static __device__ __forceinline__ half8 zero_h8() {
+    half8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = (h16)0.f;
+    return z;
+}
+
+// launchers implemented in the individual .hip files; all return 0 / negative error
+int launch_conv(const ssdn_conv_args* a, hipStream_t s);
+int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s);
+int launch_pack_input(const ssdn_pack_input_args* a, hipStream_t s);
+int launch_pool_fwd(const ssdn_pool_args* a, hipStream_t s);
+int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s);
+int launch_upsum_bwd(const ssdn_upsum_args* a, hipStream_t s);
+int launch_unrot_fwd(const ssdn_unrot_args* a, hipStream_t s);
+int launch_unrot_bwd(const ssdn_unrot_args* a, hipStream_t s);
+int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s);
+int launch_wpack(const ssdn_wpack_args* a, hipStream_t s);
+int launch_grad_pack(const ssdn_grad_pack_args* a, hipStream_t s);
+int launch_head(const ssdn_head_args* a, hipStream_t s);
+int launch_head_final(const ssdn_head_final_args* a, hipStream_t s);
+int launch_spatial_mean(const ssdn_spatial_mean_args* a, hipStream_t s);
+int launch_mse(const ssdn_mse_args* a, int masked, hipStream_t s);
+int launch_adam(const ssdn_adam_args* a, hipStream_t s);
+int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s);
+int conv_lds_bytes(const ssdn_conv_args* a);
+int wgrad_lds_bytes(const ssdn_wgrad_args* a);

@@ -1,0 +1,256 @@
+// conv_mfma.hip -- im2col-free implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x16_f16).
+//
+// One kernel serves every 3x3 / 1x1 convolution of the U-Net in both roles:
+//   forward       out = lrelu(bias + sum_t W_t * in(y+dy_t, x+dx_t))          (ShiftConv2d / Conv2d, noise_network.py:58-156,241-260)
+//   data gradient dX  = (sum_t W_t^T * dZ(y-dy_t, x-dx_t) [+ skip grad]) * lrelu'(X)   (autograd's conv backward-data)
+// The blind-spot shift, nearest-upsample and channel-concat of the reference are folded into the tap offsets and the
+// two-source tile loader; nothing is padded, cropped, upsampled or concatenated in HBM.
+//
+// GEMM view per workgroup: D[m][pixel] += A[m][k] * B[k][pixel];  A = packed weights (rows = output channels),
+// B = the input halo tile staged ONCE in LDS as NHWC fp16 (every tap is a different LDS offset of the same tile).
+//   workgroup = 256 threads = 4 waves; tile = up to 256 output pixels (2^ltn images x 2^lth rows x 2^ltw cols)
+//   wave w owns pixels [64w, 64w+64) = two 32-wide MFMA column tiles, and all MT (<=3) 32-row output-channel tiles
+//   LDS: halo tile [TN][TH+padT+padB][TW+padL+padR] pixels x (kc fp16 + 16 B pad)  +  one weight slice [32*MT][kc] (+pad)
+//   pixel / weight row stride = 16 B x odd  =>  ds_read_b128 of 16 different pixels hits 16 different 16-B bank slots.
+#include "common.h"
+
+#define CONV_THREADS 256
+
+struct ConvGeom {
+    int TW, TH, TN, HH, HW, padT, padB, padL, padR;
+    int PSTR, WSTR, NP;  // bytes, bytes, halo pixels
+    int tiles_x, tiles_y, groups_n;
+};
+
+static __host__ __device__ inline ConvGeom conv_geom(int ltw, int lth, int ltn, int ntaps, const int* dy, const int* dx,
+                                                     int N, int H, int W, int kc) {
+    ConvGeom g;
+    g.TW = 1 << ltw; g.TH = 1 << lth; g.TN = 1 << ltn;
+    int mny = 0, mxy = 0, mnx = 0, mxx = 0;
+    for (int t = 0; t < ntaps; ++t) {
+        mny = dy[t] < mny ? dy[t] : mny; mxy = dy[t] > mxy ? dy[t] : mxy;
+        mnx = dx[t] < mnx ? dx[t] : mnx; mxx = dx[t] > mxx ? dx[t] : mxx;
+    }
+    g.padT = -mny; g.padB = mxy; g.padL = -mnx; g.padR = mxx;
+    g.HH = g.TH + g.padT + g.padB;
+    g.HW = g.TW + g.padL + g.padR;
+    g.NP = g.TN * g.HH * g.HW;
+    g.PSTR = kc * 2 + 16;
+    g.WSTR = kc * 2 + 16;
+    g.tiles_x = (W + g.TW - 1) / g.TW;
+    g.tiles_y = (H + g.TH - 1) / g.TH;
+    g.groups_n = (N + g.TN - 1) / g.TN;
+    return g;
+}
+
+static __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned magic) { return __umulhi(x, magic); }
+static inline unsigned magic_of(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+
+struct ConvAux {  // host-computed helpers passed by value
+    unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
+    int lg;                 // log2(threads cooperating on one pixel / weight row when staging)
+    int cc8;                // 16-B chunks per pixel per channel chunk (= kc/8)
+    int m_base;             // first output channel of this launch (multiple of 32)
+};
+
+template <int MT>
+__global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, a.kc);
+    char* tile = smem;
+    char* wl = smem + (size_t)g.NP * g.PSTR;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
+    // tile origin
+    int bid = blockIdx.x;
+    const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
+    const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
+    const int n0 = bid * g.TN, y0 = ty_i * g.TH, x0 = tx_i * g.TW;
+
+    // this lane's two output pixels (MFMA columns)
+    int bbase[2], pn[2], py[2], px[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        int q = wave * 64 + nt * 32 + l31;
+        int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
+        pn[nt] = n0 + tn; py[nt] = y0 + ty; px[nt] = x0 + tx;
+        if (tn >= g.TN) {  // tile smaller than 256 pixels: surplus lanes compute on pixel 0 and store nothing
+            pn[nt] = a.N;
+            tn = ty = tx = 0;
+        }
+        bbase[nt] = ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * g.PSTR + kh * 16;
+    }
+    const int abase = l31 * g.WSTR + kh * 16;
+
+    f32x16 acc[MT][2];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
+
+    const int G = 1 << x.lg, sub = tid & (G - 1), grp = tid >> x.lg, ngrp = CONV_THREADS >> x.lg;
+    const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
+    const int nchunks = a.Ktot / a.kc;
+    const h16* s0 = (const h16*)a.src0.p;
+    const h16* s1 = (const h16*)a.src1.p;
+    const h16* wp = (const h16*)a.w;
+
+    for (int ch = 0; ch < nchunks; ++ch) {
+        __syncthreads();  // everyone is done reading the previous channel chunk
+        // ---- stage the input halo tile (channels [ch*kc, ch*kc+kc)) ------------------------------------------
+        if (sub < x.cc8) {
+            const int k = ch * a.kc + sub * 8;
+            for (int hp = grp; hp < g.NP; hp += ngrp) {
+                unsigned r1 = fdiv(hp, x.mg_hw);
+                int hx = hp - r1 * g.HW;
+                unsigned tn = fdiv(r1, x.mg_hh);
+                int hy = r1 - tn * g.HH;
+                int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
+                half8 v = zero_h8();
+                if (n < a.N && y >= 0 && y < a.H && xx >= 0 && xx < a.W) {
+                    if (k < a.c0) {
+                        int ys = a.up0 ? (y >> 1) : y, xs = a.up0 ? (xx >> 1) : xx;
+                        v = ld_h8(s0 + (((long long)n * H0 + ys) * W0 + xs) * a.src0.cs + a.src0.co + k);
+                    } else {
+                        v = ld_h8(s1 + (((long long)n * a.H + y) * a.W + xx) * a.src1.cs + a.src1.co + (k - a.c0));
+                    }
+                }
+                *reinterpret_cast<half8*>(tile + (size_t)hp * g.PSTR + sub * 16) = v;
+            }
+        }
+        for (int t = 0; t < a.ntaps; ++t) {
+            __syncthreads();  // tile visible (t == 0) / previous tap's weight slice no longer read
+            if (sub < x.cc8) {
+                for (int m = grp; m < MT * 32; m += ngrp) {
+                    half8 v = ld_h8(wp + ((long long)t * a.Mpad + x.m_base + m) * a.Ktot + ch * a.kc + sub * 8);
+                    *reinterpret_cast<half8*>(wl + (size_t)m * g.WSTR + sub * 16) = v;
+                }
+            }
+            __syncthreads();
+            const int toff = (a.dy[t] * g.HW + a.dx[t]) * g.PSTR;
+            const char* b0p = tile + bbase[0] + toff;
+            const char* b1p = tile + bbase[1] + toff;
+            const char* ap = wl + abase;
+            for (int s = 0; s < a.kc; s += 16) {
+                half8 b0 = *reinterpret_cast<const half8*>(b0p + s * 2);
+                half8 b1 = *reinterpret_cast<const half8*>(b1p + s * 2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    half8 av = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR + s * 2);
+                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[mt][0], 0, 0, 0);
+                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[mt][1], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- epilogue: D row = 8*(r>>2) + 4*(lane>>5) + (r&3)  (output channel), D col = lane&31 (pixel) -------------
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        const int n = pn[nt], y = py[nt], xx = px[nt];
+        if (n >= a.N || y >= a.H || xx >= a.W) continue;
+        const long long pix = ((long long)n * a.H + y) * a.W + xx;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int m = x.m_base + mt * 32 + gq * 8 + kh * 4;
+                if (m >= a.M) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[mt][nt][gq * 4 + j];
+                    if (a.bias && m + j < a.M) v[j] += a.bias[m + j];
+                    if (a.act) v[j] = lrelu(v[j]);
+                }
+                if (a.dst32) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (m + j < a.M) a.dst32[(((long long)n * a.M + m + j) * a.H + y) * a.W + xx] = v[j];
+                    continue;
+                }
+                if (a.add.p) {
+                    half4 ad = ld_h4((const h16*)a.add.p + pix * a.add.cs + a.add.co + m);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] += (float)ad[j];
+                }
+                if (a.mask.p) {
+                    half4 mk = ld_h4((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] *= lrelu_grad((float)mk[j]);
+                }
+                half4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = (h16)v[j];
+                st_h4((h16*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+            }
+        }
+    }
+}
+
+static int conv_validate(const ssdn_conv_args* a) {
+    if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("conv: ntaps out of range");
+    if (a->ltw + a->lth + a->ltn > 8 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 256 pixels");
+    if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 15)) return ssdn_set_error("conv: Ktot must equal c0+c1 and be a multiple of 16");
+    if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("conv: source channel counts must be multiples of 8");
+    if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc) return ssdn_set_error("conv: kc must be a multiple of 16 dividing Ktot");
+    if ((a->Mpad & 31) || a->M > a->Mpad) return ssdn_set_error("conv: Mpad must be a multiple of 32 and >= M");
+    if (!a->dst32 && (a->M & 3)) return ssdn_set_error("conv: fp16 output needs M %% 4 == 0");
+    if (a->up0 && ((a->H | a->W) & 1)) return ssdn_set_error("conv: upsampled source needs even H, W");
+    if (a->c1 > 0 && !a->src1.p) return ssdn_set_error("conv: src1 missing");
+    return 0;
+}
+
+int conv_lds_bytes(const ssdn_conv_args* a) {
+    if (conv_validate(a)) return -1;
+    ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
+    int mt = a->Mpad / 32;
+    if (mt > 3) mt = 3;
+    return g.NP * g.PSTR + mt * 32 * g.WSTR;
+}
+
+template <int MT>
+static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
+    size_t lds = (size_t)g.NP * g.PSTR + (size_t)MT * 32 * g.WSTR;
+    if (lds > 160 * 1024) return ssdn_set_error("conv: tiling needs %zu B of LDS (> 160 KiB)", lds);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    int grid = g.tiles_x * g.tiles_y * g.groups_n;
+    for (int by = 0; by < nblk_y; ++by) {
+        ConvAux xx = x;
+        xx.m_base = x.m_base + by * MT * 32;
+        hipLaunchKernelGGL(k_conv<MT>, dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
+    }
+    return 0;
+}
+
+int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
+    int rc = conv_validate(a);
+    if (rc) return rc;
+    ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
+    ConvAux x;
+    x.mg_hw = magic_of(g.HW);
+    x.mg_hh = magic_of(g.HH);
+    x.cc8 = a->kc / 8;
+    x.lg = 0;
+    while ((1 << x.lg) < x.cc8) ++x.lg;
+    if (x.lg > 8) return ssdn_set_error("conv: kc too large");
+    x.m_base = 0;
+    // output channels in launches of 96 (MT=3); the tail uses MT = 1 or 2
+    int full = a->Mpad / 96, rem = (a->Mpad % 96) / 32;
+    if (full) {
+        rc = conv_launch_mt<3>(a, g, x, full, s);
+        if (rc) return rc;
+    }
+    x.m_base = full * 96;
+    if (rem == 2) rc = conv_launch_mt<2>(a, g, x, 1, s);
+    else if (rem == 1) rc = conv_launch_mt<1>(a, g, x, 1, s);
+    if (rc) return rc;
+    SSDN_CHECK_HIP(hipGetLastError());
+    return 0;
+}

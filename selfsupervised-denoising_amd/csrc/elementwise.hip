@@ -1,0 +1,381 @@
+// elementwise.hip -- HBM-bound layout / routing kernels of the blind-spot U-Net (gfx950).
+// All activation traffic is NHWC fp16 moved as 16-byte (8-channel) vectors per lane.
+#include "common.h"
+
+#define EW_BLOCK 256
+static inline int ew_grid(long long n) {
+    long long g = (n + EW_BLOCK - 1) / EW_BLOCK;
+    return (int)(g < 1 ? 1 : g);
+}
+
+// ------------------------------------------------------------------------------------------------
+// PACK_INPUT: rotate-stack, NCHW f32 -> NHWC f16   (noise_network.py:187-189, utils/data.py:42-67)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pack_input(ssdn_pack_input_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = a.H, W = a.W;
+    long long total = (long long)a.R * a.B * H * W;
+    if (idx >= total) return;
+    int j = idx % W;
+    int i = (idx / W) % H;
+    int nb = idx / ((long long)W * H);
+    int r = nb / a.B, b = nb % a.B;
+    int sy, sx;  // source coordinates in the un-rotated image
+    switch (r) {
+        case 0: sy = i; sx = j; break;
+        case 1: sy = j; sx = W - 1 - i; break;          // rotate(x,90)[i,j]  = x[j, W-1-i]
+        case 2: sy = H - 1 - i; sx = W - 1 - j; break;  // rotate(x,180)[i,j] = x[H-1-i, W-1-j]
+        default: sy = H - 1 - j; sx = i; break;         // rotate(x,270)[i,j] = x[H-1-j, i]
+    }
+    h16* d = (h16*)a.dst.p + idx * a.dst.cs + a.dst.co;
+    for (int c0 = 0; c0 < a.cpad; c0 += 8) {
+        half8 v = zero_h8();
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c0 + c < a.C) v[c] = (h16)a.src[(((long long)b * a.C + c0 + c) * H + sy) * W + sx];
+        st_h8(d + c0, v);
+    }
+}
+int launch_pack_input(const ssdn_pack_input_args* a, hipStream_t s) {
+    if (a->R == 4 && a->H != a->W) return ssdn_set_error("pack_input: blind-spot rotation needs square images");
+    long long n = (long long)a->R * a->B * a->H * a->W;
+    hipLaunchKernelGGL(k_pack_input, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// POOL_FWD / POOL_BWD  (noise_network.py:64-67; models/utility.py:37-53)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_pool_fwd(ssdn_pool_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C8 = a.C >> 3, Ho = a.H >> 1, Wo = a.W >> 1;
+    long long total = (long long)a.N * Ho * Wo * C8;
+    if (idx >= total) return;
+    int c = (idx % C8) * 8;
+    long long p = idx / C8;
+    int j = p % Wo;
+    int i = (p / Wo) % Ho;
+    int n = p / ((long long)Wo * Ho);
+    const h16* src = (const h16*)a.act.p + a.act.co + c;
+    int r0 = a.shifted ? 2 * i - 1 : 2 * i;
+    float m[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) m[q] = (a.shifted && r0 < 0) ? 0.f : -65504.f;  // literal zero row takes part
+#pragma unroll
+    for (int dr = 0; dr < 2; ++dr) {
+        int y = r0 + dr;
+        if (y < 0) continue;
+#pragma unroll
+        for (int dc = 0; dc < 2; ++dc) {
+            half8 v = ld_h8(src + (((long long)n * a.H + y) * a.W + 2 * j + dc) * a.act.cs);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (float)v[q]);
+        }
+    }
+    half8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (h16)m[q];
+    st_h8((h16*)a.pooled.p + a.pooled.co + c + (((long long)n * Ho + i) * Wo + j) * a.pooled.cs, o);
+}
+int launch_pool_fwd(const ssdn_pool_args* a, hipStream_t s) {
+    if ((a->C & 7) || (a->H & 1) || (a->W & 1)) return ssdn_set_error("pool: C%%8, H%%2, W%%2 must be 0");
+    long long n = (long long)a->N * (a->H / 2) * (a->W / 2) * (a->C / 8);
+    hipLaunchKernelGGL(k_pool_fwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+__global__ void k_pool_bwd(ssdn_pool_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C8 = a.C >> 3, Ho = a.H >> 1, Wo = a.W >> 1;
+    long long total = (long long)a.N * Ho * Wo * C8;
+    if (idx >= total) return;
+    int c = (idx % C8) * 8;
+    long long p = idx / C8;
+    int j = p % Wo;
+    int i = (p / Wo) % Ho;
+    int n = p / ((long long)Wo * Ho);
+    const h16* act = (const h16*)a.act.p + a.act.co + c;
+    h16* dz = (h16*)a.dz.p + a.dz.co + c;
+    half8 g = ld_h8((const h16*)a.dpool.p + a.dpool.co + c + (((long long)n * Ho + i) * Wo + j) * a.dpool.cs);
+    int r0 = a.shifted ? 2 * i - 1 : 2 * i;
+    half8 v[4];
+    float m[8];
+    bool taken[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        m[q] = (a.shifted && r0 < 0) ? 0.f : -65504.f;
+        taken[q] = false;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int y = r0 + (k >> 1);
+        if (y < 0) { v[k] = zero_h8(); continue; }
+        v[k] = ld_h8(act + (((long long)n * a.H + y) * a.W + 2 * j + (k & 1)) * a.act.cs);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (float)v[k][q]);
+    }
+    // the zero pad row is scanned first: if it holds the max, the gradient is dropped
+    if (a.shifted && r0 < 0) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) taken[q] = (m[q] == 0.f);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int y = r0 + (k >> 1);
+        if (y < 0) continue;
+        half8 o;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            float av = (float)v[k][q];
+            bool hit = !taken[q] && av == m[q];
+            if (hit) taken[q] = true;
+            o[q] = hit ? (h16)((float)g[q] * lrelu_grad(av)) : (h16)0.f;
+        }
+        st_h8(dz + (((long long)n * a.H + y) * a.W + 2 * j + (k & 1)) * a.dz.cs, o);
+    }
+    // shifted pooling never looks at the last row: its gradient is zero
+    if (a.shifted && i == Ho - 1) {
+        half8 z = zero_h8();
+        st_h8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j) * a.dz.cs, z);
+        st_h8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j + 1) * a.dz.cs, z);
+    }
+}
+int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s) {
+    if ((a->C & 7) || (a->H & 1) || (a->W & 1)) return ssdn_set_error("pool: C%%8, H%%2, W%%2 must be 0");
+    long long n = (long long)a->N * (a->H / 2) * (a->W / 2) * (a->C / 8);
+    hipLaunchKernelGGL(k_pool_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// UPSUM_BWD: adjoint of nearest 2x upsample (+ LeakyReLU' of the producer)   (noise_network.py:102,110,120)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_upsum_bwd(ssdn_upsum_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int C8 = a.C >> 3;
+    long long total = (long long)a.N * a.H * a.W * C8;
+    if (idx >= total) return;
+    int c = (idx % C8) * 8;
+    long long p = idx / C8;
+    int j = p % a.W;
+    int i = (p / a.W) % a.H;
+    int n = p / ((long long)a.W * a.H);
+    const h16* src = (const h16*)a.src.p + a.src.co + c;
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        half8 v = ld_h8(src + (((long long)n * 2 * a.H + 2 * i + (k >> 1)) * 2 * a.W + 2 * j + (k & 1)) * a.src.cs);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) acc[q] += (float)v[q];
+    }
+    half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + p * a.mask.cs);
+    half8 o;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = (h16)(acc[q] * lrelu_grad((float)mk[q]));
+    st_h8((h16*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
+}
+int launch_upsum_bwd(const ssdn_upsum_args* a, hipStream_t s) {
+    if (a->C & 7) return ssdn_set_error("upsum: C%%8 must be 0");
+    long long n = (long long)a->N * a->H * a->W * (a->C / 8);
+    hipLaunchKernelGGL(k_upsum_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// UNROT_FWD / UNROT_BWD  (noise_network.py:213-222)
+//   aligned_r[i,j] = S_r[u,v], S_r[u,v] = u>=1 ? Y[rB+b, u-1, v] : 0
+//   r=0: (u,v)=(i,j); r=1 (rot 270): (P-1-j, i); r=2 (rot 180): (P-1-i, P-1-j); r=3 (rot 90): (j, P-1-i)
+// ------------------------------------------------------------------------------------------------
+__global__ void k_unrot_fwd(ssdn_unrot_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = a.P, C8 = a.C >> 3;
+    long long total = (long long)a.B * P * P * 4 * C8;
+    if (idx >= total) return;
+    int c = (idx % C8) * 8;
+    long long t = idx / C8;
+    int r = t & 3;
+    long long p = t >> 2;
+    int j = p % P;
+    int i = (p / P) % P;
+    int b = p / ((long long)P * P);
+    int u, v;
+    switch (r) {
+        case 0: u = i; v = j; break;
+        case 1: u = P - 1 - j; v = i; break;
+        case 2: u = P - 1 - i; v = P - 1 - j; break;
+        default: u = j; v = P - 1 - i; break;
+    }
+    half8 val = zero_h8();
+    if (u >= 1)
+        val = ld_h8((const h16*)a.src.p + a.src.co + c + ((((long long)r * a.B + b) * P + (u - 1)) * P + v) * a.src.cs);
+    st_h8((h16*)a.dst.p + a.dst.co + r * a.C + c + p * a.dst.cs, val);
+}
+int launch_unrot_fwd(const ssdn_unrot_args* a, hipStream_t s) {
+    if (a->C & 7) return ssdn_set_error("unrot: C%%8 must be 0");
+    long long n = (long long)a->B * a->P * a->P * 4 * (a->C / 8);
+    hipLaunchKernelGGL(k_unrot_fwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+__global__ void k_unrot_bwd(ssdn_unrot_args a) {
+    // dY[rB+b, y, x, c] = (y+1 < P ? dU[b, i, j, r*C + c] : 0) * lrelu'(Y),  (u,v) = (y+1, x) -> (i,j) inverse map
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int P = a.P, C8 = a.C >> 3;
+    long long total = (long long)4 * a.B * P * P * C8;
+    if (idx >= total) return;
+    int c = (idx % C8) * 8;
+    long long p = idx / C8;
+    int x = p % P;
+    int y = (p / P) % P;
+    int nb = p / ((long long)P * P);
+    int r = nb / a.B, b = nb % a.B;
+    half8 o = zero_h8();
+    int u = y + 1, v = x;
+    if (u < P) {
+        int i, j;
+        switch (r) {
+            case 0: i = u; j = v; break;
+            case 1: i = v; j = P - 1 - u; break;          // u = P-1-j, v = i
+            case 2: i = P - 1 - u; j = P - 1 - v; break;
+            default: i = P - 1 - v; j = u; break;         // u = j, v = P-1-i
+        }
+        half8 g = ld_h8((const h16*)a.src.p + a.src.co + r * a.C + c + (((long long)b * P + i) * P + j) * a.src.cs);
+        half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + p * a.mask.cs);
+#pragma unroll
+        for (int q = 0; q < 8; ++q) o[q] = (h16)((float)g[q] * lrelu_grad((float)mk[q]));
+    }
+    st_h8((h16*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
+}
+int launch_unrot_bwd(const ssdn_unrot_args* a, hipStream_t s) {
+    if (a->C & 7) return ssdn_set_error("unrot: C%%8 must be 0");
+    long long n = (long long)4 * a->B * a->P * a->P * (a->C / 8);
+    hipLaunchKernelGGL(k_unrot_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// GRAD_PACK: fp32 NCHW loss gradient -> fp16 NHWC with a power-of-two loss scale
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ float scale_from_gmax(uint32_t bits) {
+    float mx = __uint_as_float(bits);
+    if (!(mx > 0.f) || !isfinite(mx)) return 1.f;
+    // map max|g| to [8,16): 12 binades of head-room below the fp16 maximum for growth along the backward pass
+    int e;
+    frexpf(mx, &e);  // mx = f * 2^e, f in [0.5,1)
+    return ldexpf(1.f, 4 - e);
+}
+__global__ void k_grad_pack(ssdn_grad_pack_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long HW = (long long)a.H * a.W;
+    long long total = a.N * HW;
+    float scale = scale_from_gmax(*a.gmax);
+    if (idx == 0) {
+        a.scale_out[0] = scale;
+        a.scale_out[1] = 1.f / scale;
+    }
+    if (idx >= total) return;
+    int n = idx / HW;
+    long long pix = idx % HW;
+    h16* d = (h16*)a.dst.p + a.dst.co + idx * a.dst.cs;
+    for (int c0 = 0; c0 < a.cpad; c0 += 8) {
+        half8 v = zero_h8();
+#pragma unroll
+        for (int c = 0; c < 8; ++c)
+            if (c0 + c < a.C) v[c] = (h16)(a.g[((long long)n * a.C + c0 + c) * HW + pix] * scale);
+        st_h8(d + c0, v);
+    }
+}
+int launch_grad_pack(const ssdn_grad_pack_args* a, hipStream_t s) {
+    long long n = (long long)a->N * a->H * a->W;
+    hipLaunchKernelGGL(k_grad_pack, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// WPACK: fp32 OIHW master -> fp16 MFMA shadows (forward [t][m][k], dgrad [t][c][m])
+// ------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ int k_to_cin(int k, int c0, int c1_real) {
+    if (k < c0) return k;
+    int r = k - c0;
+    return r < c1_real ? c0 + r : -1;
+}
+__global__ void k_wpack(ssdn_wpack_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long nf = (long long)a.ntaps * a.Mpad_f * a.Ktot;
+    long long nd = a.wd ? (long long)a.ntaps * a.Mpad_d * a.Kd : 0;
+    if (idx < nf) {
+        int k = idx % a.Ktot;
+        int m = (idx / a.Ktot) % a.Mpad_f;
+        int t = idx / ((long long)a.Ktot * a.Mpad_f);
+        int ci = k_to_cin(k, a.c0, a.c1_real);
+        float v = (m < a.M && ci >= 0) ? a.w[((long long)m * a.cin + ci) * a.ntaps + t] : 0.f;
+        ((h16*)a.wf)[idx] = (h16)v;
+    } else if (idx < nf + nd) {
+        long long e = idx - nf;
+        int m = e % a.Kd;                       // reduction index of the dgrad GEMM = forward output channel
+        int c = (e / a.Kd) % a.Mpad_d;          // output index of the dgrad GEMM = forward input channel slot
+        int t = e / ((long long)a.Kd * a.Mpad_d);
+        int ci = c < a.Ktot ? k_to_cin(c, a.c0, a.c1_real) : -1;
+        float v = (m < a.M && ci >= 0) ? a.w[((long long)m * a.cin + ci) * a.ntaps + t] : 0.f;
+        ((h16*)a.wd)[e] = (h16)v;
+    }
+}
+int launch_wpack(const ssdn_wpack_args* a, hipStream_t s) {
+    long long n = (long long)a->ntaps * a->Mpad_f * a->Ktot + (a->wd ? (long long)a->ntaps * a->Mpad_d * a->Kd : 0);
+    hipLaunchKernelGGL(k_wpack, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// WREDUCE: ordered sum of the per-workgroup weight-gradient slabs -> fp32 OIHW gradient
+// ------------------------------------------------------------------------------------------------
+__global__ void k_wreduce(ssdn_wreduce_args a) {
+    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long nw = (long long)a.M * a.cin * a.ntaps;
+    float inv = a.inv_scale ? *a.inv_scale : 1.f;
+    if (idx < nw) {
+        int t = idx % a.ntaps;
+        int ci = (idx / a.ntaps) % a.cin;
+        int m = idx / ((long long)a.ntaps * a.cin);
+        int k = ci;  // real channels are contiguous in k (padding sits at the tail of the 2nd source only)
+        long long off = ((long long)t * a.Mpad + m) * a.Kpad + k;
+        long long stride = (long long)a.ntaps * a.Mpad * a.Kpad;
+        float acc = 0.f;
+        for (int s = 0; s < a.nslabs; ++s) acc += a.slab[s * stride + off];
+        a.gw[((long long)(a.m_off + m) * a.cin_full + a.c_off + ci) * a.ntaps + t] = acc * inv;
+    } else if (idx < nw + a.M && a.gb) {
+        int m = idx - nw;
+        float acc = 0.f;
+        for (int s = 0; s < a.nslabs; ++s) acc += a.bslab[(long long)s * a.Mpad + m];
+        a.gb[a.m_off + m] = acc * inv;
+    }
+}
+int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s) {
+    long long n = (long long)a->M * a->cin * a->ntaps + a->M;
+    hipLaunchKernelGGL(k_wreduce, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// ADAM  (train.py:100-107,202): one fused pass over the flat master buffer
+// ------------------------------------------------------------------------------------------------
+__global__ void k_adam(ssdn_adam_args a) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    long long stride = (long long)gridDim.x * blockDim.x;
+    float inv_bc2s = 1.f / sqrtf(a.bc2);
+    float step = a.lr / a.bc1;
+    for (; i < a.n; i += stride) {
+        float g = a.g[i] * a.gscale;
+        float m = a.b1 * a.m[i] + (1.f - a.b1) * g;
+        float v = a.b2 * a.v[i] + (1.f - a.b2) * g * g;
+        a.m[i] = m;
+        a.v[i] = v;
+        a.p[i] -= step * m / (sqrtf(v) * inv_bc2s + a.eps);
+    }
+}
+int launch_adam(const ssdn_adam_args* a, hipStream_t s) {
+    int g = ew_grid(a->n);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_adam, dim3(g), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}

@@ -1,0 +1,267 @@
+"""Device side of the op-list plans: owns the HBM buffers (allocated through torch, used as a plain device allocator),
+materialises `ssdn.hip.graph` Op records into the C structs of include/ssdn_hip.h and executes them with ONE call
+into libssdn_hip.so per phase (forward / backward / optimiser).  No torch compute op is on this path.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import lib as L
+from .graph import NetPlan, Op, View
+
+
+def _ptr(t: torch.Tensor, byte_off: int = 0) -> int:
+    return t.data_ptr() + byte_off
+
+
+class OpList:
+    """A materialised op list: a ctypes array of ssdn_op plus the argument structs it points to."""
+
+    def __init__(self, recs):
+        self.args = [a for _, a in recs]                      # keep the structs alive
+        self.arr = (L.OpRec * max(1, len(recs)))()
+        for i, (ty, a) in enumerate(recs):
+            self.arr[i].type = L.OP[ty]
+            self.arr[i].args = C.cast(C.pointer(a), C.c_void_p)
+        self.n = len(recs)
+
+    def run(self, stream: int = 0):
+        if self.n:
+            L.check(L.load().ssdn_run_ops(self.arr, self.n, C.c_void_p(stream)))
+
+
+def current_stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class DeviceNet:
+    """One NoiseNetwork instance on the device for a fixed input shape: buffers + materialised fwd/bwd/pack op lists."""
+
+    DT = {"act": torch.float16, "f16": torch.float16, "f32": torch.float32, "u32": torch.int32, "i64": torch.int64}
+
+    def __init__(self, plan: NetPlan, device, params: torch.Tensor, grads: Optional[torch.Tensor],
+                 shared: Optional[Dict[str, torch.Tensor]] = None):
+        self.plan, self.device = plan, device
+        self.params, self.grads = params, grads
+        self.t: Dict[str, torch.Tensor] = dict(shared or {})
+        for name, spec in plan.tensors.items():
+            if name in self.t:
+                continue
+            # zero-initialised once: padding channels / never-written slab corners must be finite
+            self.t[name] = torch.zeros(spec.shape, dtype=self.DT[spec.kind], device=device)
+        self.fwd = OpList([self._mat(op) for op in plan.fwd])
+        self.bwd = OpList([self._mat(op) for op in plan.bwd])
+        self.pack = OpList([self._mat(op) for op in plan.pack])
+
+    # ---- helpers ------------------------------------------------------------------------------------------
+    def tensor(self, short: str) -> torch.Tensor:
+        return self.t[self.plan.prefix + short]
+
+    def _view(self, v: Optional[View]) -> L.View:
+        if v is None:
+            return L.View(None, 0, 0)
+        t = self.t[v.t]
+        return L.View(_ptr(t), t.shape[-1], v.co)
+
+    def _pp(self, off_floats: int) -> int:
+        return _ptr(self.params, 4 * (self.plan.param_base + off_floats))
+
+    def _gp(self, off_floats: int) -> int:
+        return _ptr(self.grads, 4 * (self.plan.param_base + off_floats))
+
+    def _layer(self, name):
+        return next(l for l in self.plan.layers if l.name == name)
+
+    def _mat(self, op: Op):
+        a = op.a
+        P = self.plan.prefix
+        if op.type == "pack_input":
+            return op.type, L.PackInputArgs(_ptr(self.t[a["src"]]), self._view(a["dst"]), a["B"], a["C"], a["H"], a["W"], a["R"], a["cpad"])
+        if op.type == "conv":
+            l = self._layer(a["layer"])
+            s = L.ConvArgs()
+            s.src0, s.src1 = self._view(a["src0"]), self._view(a["src1"])
+            s.c0, s.c1, s.up0 = a["c0"], a["c1"], a["up0"]
+            s.N, s.H, s.W = a["N"], a["H"], a["W"]
+            s.ntaps = len(a["taps"])
+            for i, (dy, dx) in enumerate(a["taps"]):
+                s.dy[i], s.dx[i] = dy, dx
+            s.w = _ptr(self.t[P + ("wf/" if a["role"] == "fwd" else "wd/") + a["layer"]])
+            s.M, s.Mpad, s.Ktot = a["M"], a["Mpad"], a["Ktot"]
+            s.bias = self._pp(l.b_off) if a["bias"] else None
+            s.act = a["act"]
+            s.mask, s.add, s.dst = self._view(a["mask"]), self._view(a["add"]), self._view(a["dst"])
+            s.dst32 = _ptr(self.t[a["dst32"]]) if a["dst32"] is not None else None
+            s.ltw, s.lth, s.ltn, s.kc = a["ltw"], a["lth"], a["ltn"], a["kc"]
+            if L.load().ssdn_conv_lds_bytes(C.byref(s)) < 0:
+                raise L.SsdnHipError("conv %s/%s: %s" % (a["layer"], a["role"], L.load().ssdn_last_error().decode()))
+            return op.type, s
+        if op.type in ("pool_fwd", "pool_bwd"):
+            return op.type, L.PoolArgs(self._view(a["act"]), self._view(a.get("pooled")), self._view(a.get("dpool")),
+                                       self._view(a.get("dz")), a["N"], a["H"], a["W"], a["C"], a["shifted"])
+        if op.type == "upsum_bwd":
+            return op.type, L.UpsumArgs(self._view(a["src"]), self._view(a["mask"]), self._view(a["dst"]), a["N"], a["H"], a["W"], a["C"])
+        if op.type in ("unrot_fwd", "unrot_bwd"):
+            return op.type, L.UnrotArgs(self._view(a["src"]), self._view(a["dst"]), self._view(a.get("mask")), a["B"], a["P"], a["C"])
+        if op.type == "wgrad":
+            s = L.WgradArgs()
+            s.dz, s.src0, s.src1 = self._view(a["dz"]), self._view(a["src0"]), self._view(a["src1"])
+            s.c0, s.c1, s.up0 = a["c0"], a["c1"], a["up0"]
+            s.N, s.H, s.W = a["N"], a["H"], a["W"]
+            s.ntaps = len(a["taps"])
+            for i, (dy, dx) in enumerate(a["taps"]):
+                s.dy[i], s.dx[i] = dy, dx
+            s.M, s.Mpad, s.Ktot, s.Kpad = a["M"], a["Mpad"], a["Ktot"], a["Kpad"]
+            s.slab, s.bslab = _ptr(self.t[P + "slab"]), _ptr(self.t[P + "bslab"])
+            s.nslabs = a["nslabs"]
+            s.ltw, s.lth, s.ltn = a["ltw"], a["lth"], a["ltn"]
+            if L.load().ssdn_wgrad_lds_bytes(C.byref(s)) < 0:
+                raise L.SsdnHipError("wgrad %s: %s" % (a["layer"], L.load().ssdn_last_error().decode()))
+            return op.type, s
+        if op.type == "wreduce":
+            l = self._layer(a["layer"])
+            return op.type, L.WreduceArgs(_ptr(self.t[P + "slab"]), _ptr(self.t[P + "bslab"]), a["nslabs"], a["ntaps"], a["M"],
+                                          a["Mpad"], a["Kpad"], a["cin"], a["cin_full"], a["m_off"], a["c_off"],
+                                          self._gp(l.w_off), self._gp(l.b_off) if a["with_bias"] else None,
+                                          _ptr(self.t[P + "scale"], 4))
+        if op.type == "wpack":
+            l = self._layer(a["layer"])
+            return op.type, L.WpackArgs(self._pp(l.w_off), _ptr(self.t[P + "wf/" + l.name]),
+                                        _ptr(self.t[P + "wd/" + l.name]) if a["need_d"] else None, a["M"], a["cin"], a["ntaps"],
+                                        a["c0"], a["c1_real"], a["Mpad_f"], a["Ktot"], a["Mpad_d"], a["Kd"])
+        if op.type == "grad_pack":
+            return op.type, L.GradPackArgs(_ptr(self.t[a["g"]]), self._view(a["dst"]), a["N"], a["C"], a["H"], a["W"], a["cpad"],
+                                           _ptr(self.t[P + "gmax"]), _ptr(self.t[P + "scale"]))
+        raise ValueError("unknown op type " + op.type)
+
+
+STYLE = {"gauss": 0, "poisson": 1}
+MODE = {"known": 0, "const": 1, "var": 2}
+
+
+class DenoiserEngine:
+    """Everything one Denoiser configuration needs on one GPU for one input shape: the main net, the optional sigma
+    estimator, the loss head, the fused Adam pass -- as four op lists (fwd+loss, bwd, optimiser, eval)."""
+
+    def __init__(self, pipeline: str, channels: int, blindspot: bool, style: str, mode: str, B: int, H: int, W: int,
+                 device, params: torch.Tensor, grads: torch.Tensor, adam_m: torch.Tensor, adam_v: torch.Tensor,
+                 n_main: int, n_sigma: int, has_est: bool, train: bool = True, ncoords: int = 64):
+        self.pipeline, self.C, self.blindspot, self.mode = pipeline, channels, blindspot, mode
+        self.style = "poisson" if style.startswith("poisson") else "gauss"
+        self.B, self.H, self.W, self.device, self.train = B, H, W, device, train
+        self.params, self.grads, self.m, self.v = params, grads, adam_m, adam_v
+        lib = L.load()
+        cus = lib.ssdn_device_cus()
+        if cus <= 0:
+            raise L.SsdnHipError("no HIP device: " + lib.ssdn_last_error().decode())
+        cout = channels + channels * (channels + 1) // 2 if pipeline == "ssdn" else channels
+        f32 = dict(dtype=torch.float32, device=device)
+        self.inp = torch.zeros((B, channels, H, W), **f32)
+        self.main = DeviceNet(NetPlan("m/", channels, cout, blindspot, B, H, W, cus=cus, train=train, param_base=0),
+                              device, params, grads, shared={"m/in32": self.inp})
+        self.sigma = None
+        if pipeline == "ssdn" and mode == "var":
+            self.sigma = DeviceNet(NetPlan("s/", channels, 1, False, B, H, W, cus=cus, train=train, param_base=n_main),
+                                   device, params, grads, shared={"s/in32": self.inp})
+        self.est_off = n_main + n_sigma if has_est else None
+        # loss-side buffers
+        self.loss = torch.zeros((B, 1), **f32)
+        self.ref = torch.zeros((B, channels, H, W), **f32)
+        self.noise_param = torch.zeros((B,), **f32)
+        self.coords = torch.zeros((ncoords, 2), dtype=torch.int64, device=device)
+        self.ncoords = ncoords
+        self.nchunks = max(1, min(64, (H * W) // 1024))
+        self.partial = torch.zeros((B, self.nchunks, 2), **f32)
+        self.est_raw = torch.zeros((B,), **f32)
+        self.g_est_var = torch.zeros((B,), **f32)
+        self.mu = torch.zeros((B, channels, H, W), **f32)
+        self.pme = torch.zeros((B, channels, H, W), **f32)
+        self.model_std = torch.zeros((B, H, W), **f32)
+        self.noise_std = torch.zeros((B, H, W) if self.style == "poisson" else (B,), **f32)
+        self.zero_buf = torch.zeros((8,), dtype=torch.int32, device=device)   # unused gmax sink for eval
+        self._adam_args = None
+        self.ops_loss = OpList(self._loss_ops(want_grad=train))
+        self.ops_opt = OpList(self._opt_ops()) if train else None
+
+    # ---- op construction -----------------------------------------------------------------------------------
+    def _gmax(self, net: Optional[DeviceNet]):
+        if net is not None and self.train:
+            return _ptr(net.tensor("gmax"))
+        return _ptr(self.zero_buf)
+
+    def _loss_ops(self, want_grad: bool):
+        recs = []
+        B, Cn, H, W = self.B, self.C, self.H, self.W
+        out32 = self.main.tensor("out32")
+        g32 = _ptr(self.main.tensor("g32")) if want_grad else None
+        if want_grad:
+            recs.append(("zero", L.ZeroArgs(_ptr(self.main.tensor("gmax")), 16)))
+            if self.sigma is not None:
+                recs.append(("zero", L.ZeroArgs(_ptr(self.sigma.tensor("gmax")), 16)))
+        if self.pipeline == "ssdn":
+            est_ptr = None
+            if self.mode == "var":
+                recs.append(("spatial_mean", L.SpatialMeanArgs(_ptr(self.sigma.tensor("out32")), _ptr(self.est_raw), B, H * W)))
+                est_ptr = _ptr(self.est_raw)
+            elif self.mode == "const":
+                est_ptr = _ptr(self.params, 4 * self.est_off)
+            recs.append(("head_ssdn", L.HeadArgs(_ptr(out32), _ptr(self.inp), _ptr(self.noise_param), est_ptr, B, Cn, H, W,
+                                                  STYLE[self.style], MODE[self.mode], int(want_grad), _ptr(self.mu), _ptr(self.pme),
+                                                  _ptr(self.model_std), _ptr(self.noise_std), g32, _ptr(self.partial),
+                                                  self.nchunks, self._gmax(self.main))))
+            g_est = None
+            if want_grad and self.mode == "const":
+                g_est = _ptr(self.grads, 4 * self.est_off)
+            elif want_grad and self.mode == "var":
+                g_est = _ptr(self.g_est_var)
+            recs.append(("head_final", L.HeadFinalArgs(_ptr(self.partial), B, self.nchunks, H, W, MODE[self.mode], _ptr(self.loss), g_est,
+                                                        _ptr(self.sigma.tensor("g32")) if (want_grad and self.sigma is not None) else None,
+                                                        self._gmax(self.sigma) if self.sigma is not None else None)))
+        elif self.pipeline == "mse":
+            recs.append(("mse", L.MseArgs(_ptr(out32), _ptr(self.ref), None, 0, B, Cn, H, W, _ptr(self.loss), g32, self._gmax(self.main))))
+        elif self.pipeline == "mask_mse":
+            recs.append(("mask_mse", L.MseArgs(_ptr(out32), _ptr(self.ref), _ptr(self.coords), self.ncoords, B, Cn, H, W, _ptr(self.loss),
+                                               g32, self._gmax(self.main))))
+        else:
+            raise NotImplementedError("Unsupported processing pipeline")
+        return recs
+
+    def _opt_ops(self):
+        self._adam_args = L.AdamArgs(_ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.params.numel(),
+                                     0.0, 0.9, 0.99, 1e-8, 1.0, 1.0, 1.0)
+        return [("adam", self._adam_args)]
+
+    # ---- execution -----------------------------------------------------------------------------------------
+    def repack(self, stream=None):
+        s = current_stream() if stream is None else stream
+        self.main.pack.run(s)
+        if self.sigma is not None:
+            self.sigma.pack.run(s)
+
+    def forward(self, stream=None):
+        s = current_stream() if stream is None else stream
+        self.main.fwd.run(s)
+        if self.sigma is not None:
+            self.sigma.fwd.run(s)
+        self.ops_loss.run(s)
+
+    def net_forward_only(self, stream=None):
+        s = current_stream() if stream is None else stream
+        self.main.fwd.run(s)
+
+    def backward(self, stream=None):
+        s = current_stream() if stream is None else stream
+        self.main.bwd.run(s)
+        if self.sigma is not None:
+            self.sigma.bwd.run(s)
+
+    def adam(self, lr: float, step: int, gscale: float = 1.0, stream=None):
+        a = self._adam_args
+        a.lr, a.bc1, a.bc2, a.gscale = lr, 1.0 - 0.9 ** step, 1.0 - 0.99 ** step, gscale
+        s = current_stream() if stream is None else stream
+        self.ops_opt.run(s)
+        self.repack(s)

@@ -1,0 +1,418 @@
+"""Lowering of the blind-spot U-Net (+ loss heads, optimiser) to the flat op list executed by libssdn_hip.so.
+
+The reference builds an autograd graph of ~200 ATen ops per step (NoiseNetwork.forward,
+/root/reference/ssdn/ssdn/models/noise_network.py:186-226; Denoiser.run_pipeline, denoiser.py:128-397).  Here the
+same computation is planned ONCE per (batch, patch size) into a static list of `Op` records -- backend neutral:
+`ssdn.hip.engine` turns them into `ssdn_op` C structs holding device pointers, and the test-only interpreter
+(oracle/interp.py) executes the very same records on the CPU to check the lowering against the oracle.
+
+Nothing here touches a device; this module is pure Python.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Tuple
+
+LDS_LIMIT = 160 * 1024
+TAPS_BLIND = [(ky - 2, kx - 1) for ky in range(3) for kx in range(3)]   # ShiftConv2d: in[y+ky-2, x+kx-1]
+TAPS_PLAIN = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
+TAPS_1x1 = [(0, 0)]
+
+
+def ceil_to(v: int, m: int) -> int:
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class TSpec:
+    """A tensor of the plan.  kind 'act': NHWC fp16 [N,H,W,C]; 'f32': flat fp32; 'f16': flat fp16; 'u32'; 'i64'."""
+    name: str
+    kind: str
+    shape: Tuple[int, ...]
+
+
+@dataclass
+class View:
+    """Channel-slice view of an 'act' tensor (never a copy)."""
+    t: str
+    co: int = 0
+
+
+@dataclass
+class Op:
+    type: str
+    a: dict = field(default_factory=dict)
+
+
+@dataclass
+class Layer:
+    name: str          # reference state_dict prefix, e.g. 'decode_block_1.0'
+    M: int             # output channels
+    cin: int           # real input channels
+    k: int             # kernel size (3 or 1)
+    c0: int            # channels of source 0 in the packed K axis
+    c1: int            # channels of source 1 in the packed K axis (padded to a multiple of 16 - c0 % 16 ...)
+    c1_real: int
+    w_off: int = 0     # offsets (floats) into the flat parameter buffer
+    b_off: int = 0
+
+    @property
+    def ntaps(self):
+        return self.k * self.k
+
+    @property
+    def Ktot(self):
+        return self.c0 + self.c1
+
+    @property
+    def Mpad_f(self):
+        return ceil_to(self.M, 32)
+
+    @property
+    def Kd(self):
+        return ceil_to(self.M, 16)      # reduction length of the data-gradient GEMM
+
+
+def net_layers(in_channels: int, out_channels: int, blindspot: bool) -> List[Layer]:
+    """Same order as the reference modules (noise_network.py:69-156) == oracle/restate.layer_table."""
+    c = in_channels
+    cpad = 16
+    nin = 384 if blindspot else 96
+    L = [
+        Layer("encode_block_1.0", 48, c, 3, cpad, 0, 0),
+        Layer("encode_block_1.2", 48, 48, 3, 48, 0, 0),
+        Layer("encode_block_2.0", 48, 48, 3, 48, 0, 0),
+        Layer("encode_block_3.0", 48, 48, 3, 48, 0, 0),
+        Layer("encode_block_4.0", 48, 48, 3, 48, 0, 0),
+        Layer("encode_block_5.0", 48, 48, 3, 48, 0, 0),
+        Layer("encode_block_6.0", 48, 48, 3, 48, 0, 0),
+        Layer("decode_block_5.0", 96, 96, 3, 48, 48, 48),
+        Layer("decode_block_5.2", 96, 96, 3, 96, 0, 0),
+        Layer("decode_block_4.0", 96, 144, 3, 96, 48, 48),
+        Layer("decode_block_4.2", 96, 96, 3, 96, 0, 0),
+        Layer("decode_block_3.0", 96, 144, 3, 96, 48, 48),
+        Layer("decode_block_3.2", 96, 96, 3, 96, 0, 0),
+        Layer("decode_block_2.0", 96, 144, 3, 96, 48, 48),
+        Layer("decode_block_2.2", 96, 96, 3, 96, 0, 0),
+        Layer("decode_block_1.0", 96, 96 + c, 3, 96, cpad, c),
+        Layer("decode_block_1.2", 96, 96, 3, 96, 0, 0),
+        Layer("output_block.0", nin, nin, 1, nin, 0, 0),
+        Layer("output_block.2", 96, nin, 1, nin, 0, 0),
+        Layer("output_block.4", out_channels, 96, 1, 96, 0, 0),
+    ]
+    # first layer: the only source is the 16-channel padded input, of which `c` channels are real
+    L[0].c0, L[0].c1, L[0].c1_real = 0, cpad, c
+    off = 0
+    for l in L:
+        l.w_off = off
+        off += l.M * l.cin * l.k * l.k
+        l.b_off = off
+        off += l.M
+    return L
+
+
+def net_param_count(layers: List[Layer]) -> int:
+    return layers[-1].b_off + layers[-1].M
+
+
+# --------------------------------------------------------------------------------------------------------------
+# tiling
+# --------------------------------------------------------------------------------------------------------------
+
+def _pads(taps):
+    dys = [t[0] for t in taps]
+    dxs = [t[1] for t in taps]
+    return max(0, -min(dys)), max(0, max(dys)), max(0, -min(dxs)), max(0, max(dxs))
+
+
+def _pow2ceil_log(v: int) -> int:
+    l = 0
+    while (1 << l) < v:
+        l += 1
+    return l
+
+
+def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT):
+    """Pick (ltw, lth, ltn, kc) for SSDN_OP_CONV: <= 256 pixels per workgroup, LDS = halo tile + one weight slice."""
+    padT, padB, padL, padR = _pads(taps)
+    mt = min(3, Mpad // 32)
+    best = None
+    kcs = [kc for kc in range(16, Ktot + 1, 16) if Ktot % kc == 0]
+    for ltw in range(0, min(5, _pow2ceil_log(W)) + 1):
+        for lth in range(0, min(8 - ltw, _pow2ceil_log(H)) + 1):
+            for ltn in range(0, min(8 - ltw - lth, _pow2ceil_log(N)) + 1):
+                TW, TH, TN = 1 << ltw, 1 << lth, 1 << ltn
+                tiles = -(-W // TW) * -(-H // TH) * -(-N // TN)
+                util = (N * H * W) / (tiles * 256.0)       # MFMA lanes doing useful work
+                NP = TN * (TH + padT + padB) * (TW + padL + padR)
+                for kc in kcs:
+                    lds = NP * (kc * 2 + 16) + mt * 32 * (kc * 2 + 16)
+                    if lds > budget:
+                        continue
+                    halo = NP / float(TN * TH * TW)
+                    # prefer: high utilisation, then whole-K residency (fewer barriers), then small halo, then wide tiles
+                    key = (round(util, 3), kc, -round(halo, 3), ltw)
+                    if best is None or key > best[0]:
+                        best = (key, (ltw, lth, ltn, kc))
+    if best is None:
+        raise ValueError("no conv tiling fits in LDS for N=%d H=%d W=%d Ktot=%d" % (N, H, W, Ktot))
+    return best[1]
+
+
+def choose_wgrad_tile(N, H, W, taps, Kpad, Mpad, budget=LDS_LIMIT):
+    padT, padB, padL, padR = _pads(taps)
+    best = None
+    for ltw in range(0, min(5, _pow2ceil_log(W)) + 1):
+        for lth in range(0, min(8 - ltw, _pow2ceil_log(H)) + 1):
+            for ltn in range(max(0, 4 - ltw - lth), 8 - ltw - lth + 1):   # the kernel needs >= 16 pixels per tile
+                if ltn > max(_pow2ceil_log(N), 4 - ltw - lth):
+                    continue                                             # surplus images would only be masked lanes
+                TW, TH, TN = 1 << ltw, 1 << lth, 1 << ltn
+                tiles = -(-W // TW) * -(-H // TH) * -(-N // TN)
+                util = (N * H * W) / float(tiles * TN * TH * TW)
+                NP = TN * (TH + padT + padB) * (TW + padL + padR)
+                lds = NP * (Kpad * 2 + 16) + TN * TH * TW * (Mpad * 2 + 16) + 64
+                if lds > budget:
+                    continue
+                key = (round(util, 3), TN * TH * TW, -NP, ltw)
+                if best is None or key > best[0]:
+                    best = (key, (ltw, lth, ltn), tiles)
+    if best is None:
+        raise ValueError("no wgrad tiling fits in LDS")
+    return best[1], best[2]
+
+
+# --------------------------------------------------------------------------------------------------------------
+# the plan
+# --------------------------------------------------------------------------------------------------------------
+
+class NetPlan:
+    """Forward / backward op lists of ONE NoiseNetwork instance for a fixed input shape.
+
+    prefix   unique tensor-name prefix (a Denoiser owns up to two nets)
+    B,H,W    input batch / spatial size (H == W when blindspot)
+    cus      compute units of the device (sizes the persistent wgrad grids)
+    """
+
+    def __init__(self, prefix: str, in_channels: int, out_channels: int, blindspot: bool, B: int, H: int, W: int,
+                 cus: int = 256, train: bool = True, param_base: int = 0):
+        if H % 32 or W % 32:
+            raise ValueError("input height/width must be multiples of 32 (NoiseNetwork.input_wh_mul)")
+        if blindspot and H != W:
+            raise ValueError("blind-spot mode needs square inputs")
+        self.prefix, self.C, self.Cout, self.blindspot = prefix, in_channels, out_channels, blindspot
+        self.B, self.H, self.W, self.cus, self.train = B, H, W, cus, train
+        self.R = 4 if blindspot else 1
+        self.N = self.R * B
+        self.layers = net_layers(in_channels, out_channels, blindspot)
+        self.nparams = net_param_count(self.layers)
+        self.param_base = param_base          # offset of this net inside the owner's flat parameter buffer
+        self.taps3 = TAPS_BLIND if blindspot else TAPS_PLAIN
+        self.tensors: Dict[str, TSpec] = {}
+        self.fwd: List[Op] = []
+        self.bwd: List[Op] = []
+        self.pack: List[Op] = []
+        self.max_slab = 0
+        self.max_bslab = 0
+        self._build()
+
+    # ---- helpers -------------------------------------------------------------------------------------------
+    def T(self, name, kind, shape):
+        full = self.prefix + name
+        self.tensors[full] = TSpec(full, kind, tuple(int(s) for s in shape))
+        return full
+
+    def act(self, name, N, H, W, C):
+        return self.T(name, "act", (N, H, W, C))
+
+    def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
+              bias=True, act=True, mask=None, add=None):
+        Ktot = c0 + c1
+        Mpad = ceil_to(M, 32)
+        ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad)
+        lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
+                                   taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
+                                   dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc)))
+
+    def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
+               m_off=0, c_off=0, with_bias=True):
+        """One SSDN_OP_WGRAD + SSDN_OP_WREDUCE pair covering output channels [m_off, m_off+M) x input channels
+        [c_off, c_off+cin_real) of `layer` (M <= 96, Ktot <= 96)."""
+        Ktot = c0 + c1
+        Kpad = ceil_to(Ktot, 32)
+        Mpad = ceil_to(Mz, 32)
+        (ltw, lth, ltn), ntiles = choose_wgrad_tile(N, H, W, taps, Kpad, Mpad)
+        nslabs = max(1, min(ntiles, self.cus))
+        ntaps = len(taps)
+        self.max_slab = max(self.max_slab, nslabs * ntaps * Mpad * Kpad)
+        self.max_bslab = max(self.max_bslab, nslabs * Mpad)
+        M_real = min(Mz, layer.M - m_off)
+        self.bwd.append(Op("wgrad", dict(layer=layer.name, dz=dz, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
+                                         taps=list(taps), M=Mz, Mpad=Mpad, Ktot=Ktot, Kpad=Kpad, nslabs=nslabs,
+                                         ltw=ltw, lth=lth, ltn=ltn)))
+        self.bwd.append(Op("wreduce", dict(layer=layer.name, nslabs=nslabs, ntaps=ntaps, M=M_real, Mpad=Mpad, Kpad=Kpad,
+                                           cin=cin_real, cin_full=layer.cin, m_off=m_off, c_off=c_off, with_bias=with_bias)))
+
+    # ---- construction --------------------------------------------------------------------------------------
+    def _build(self):
+        B, N, H, W, C = self.B, self.N, self.H, self.W, self.C
+        L = {l.name: l for l in self.layers}
+        t3 = self.taps3
+        bs = self.blindspot
+        f = self.fwd
+
+        # ---------------- forward ----------------
+        self.T("in32", "f32", (B, C, H, W))
+        x16 = self.act("x16", N, H, W, 16)
+        f.append(Op("pack_input", dict(src=self.prefix + "in32", dst=View(x16), B=B, C=C, H=H, W=W, R=self.R, cpad=16)))
+
+        def enc(name, lname, src, cin_slots, h, w):
+            t = self.act(name, N, h, w, 48)
+            self._conv(f, L[lname], "fwd", View(src), cin_slots, 0, None, 0, N, h, w, t3, 48, dst=View(t))
+            return t
+
+        def pool(name, src, h, w):
+            t = self.act(name, N, h // 2, w // 2, 48)
+            f.append(Op("pool_fwd", dict(act=View(src), pooled=View(t), N=N, H=h, W=w, C=48, shifted=int(bs))))
+            return t
+
+        e0 = enc("e0", "encode_block_1.0", x16, 16, H, W)
+        e1 = enc("e1", "encode_block_1.2", e0, 48, H, W)
+        p1 = pool("p1", e1, H, W)
+        e2 = enc("e2", "encode_block_2.0", p1, 48, H // 2, W // 2)
+        p2 = pool("p2", e2, H // 2, W // 2)
+        e3 = enc("e3", "encode_block_3.0", p2, 48, H // 4, W // 4)
+        p3 = pool("p3", e3, H // 4, W // 4)
+        e4 = enc("e4", "encode_block_4.0", p3, 48, H // 8, W // 8)
+        p4 = pool("p4", e4, H // 8, W // 8)
+        e5 = enc("e5", "encode_block_5.0", p4, 48, H // 16, W // 16)
+        p5 = pool("p5", e5, H // 16, W // 16)
+        e6 = enc("e6", "encode_block_6.0", p5, 48, H // 32, W // 32)
+
+        def dec(name_a, name_b, la, lb, up_src, c_up, skip, c_skip, h, w):
+            ta = self.act(name_a, N, h, w, 96)
+            self._conv(f, L[la], "fwd", View(up_src), c_up, 1, View(skip), c_skip, N, h, w, t3, 96, dst=View(ta))
+            tb = self.act(name_b, N, h, w, 96)
+            self._conv(f, L[lb], "fwd", View(ta), 96, 0, None, 0, N, h, w, t3, 96, dst=View(tb))
+            return ta, tb
+
+        d5a, d5b = dec("d5a", "d5b", "decode_block_5.0", "decode_block_5.2", e6, 48, p4, 48, H // 16, W // 16)
+        d4a, d4b = dec("d4a", "d4b", "decode_block_4.0", "decode_block_4.2", d5b, 96, p3, 48, H // 8, W // 8)
+        d3a, d3b = dec("d3a", "d3b", "decode_block_3.0", "decode_block_3.2", d4b, 96, p2, 48, H // 4, W // 4)
+        d2a, d2b = dec("d2a", "d2b", "decode_block_2.0", "decode_block_2.2", d3b, 96, p1, 48, H // 2, W // 2)
+        d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W)
+
+        nin = 384 if bs else 96
+        if bs:
+            u = self.act("u", B, H, W, 384)
+            f.append(Op("unrot_fwd", dict(src=View(d1b), dst=View(u), B=B, P=H, C=96)))
+            head_in = u
+        else:
+            head_in = d1b
+        na = self.act("na", B, H, W, nin)
+        self._conv(f, L["output_block.0"], "fwd", View(head_in), nin, 0, None, 0, B, H, W, TAPS_1x1, nin, dst=View(na))
+        nb = self.act("nb", B, H, W, 96)
+        self._conv(f, L["output_block.2"], "fwd", View(na), nin, 0, None, 0, B, H, W, TAPS_1x1, 96, dst=View(nb))
+        out32 = self.T("out32", "f32", (B, self.Cout, H, W))
+        self._conv(f, L["output_block.4"], "fwd", View(nb), 96, 0, None, 0, B, H, W, TAPS_1x1, self.Cout, dst32=out32, act=False)
+
+        # ---------------- weight shadows ----------------
+        for l in self.layers:
+            need_d = l.name != "encode_block_1.0"
+            # dgrad GEMM: rows = the forward input-channel slots that need a gradient
+            rows = l.Ktot
+            if l.name == "decode_block_1.0":
+                rows = 96   # the network input needs no gradient
+            Mpad_d = ceil_to(rows, 32)
+            self.T("wf/" + l.name, "f16", (l.ntaps * l.Mpad_f * l.Ktot,))
+            if need_d:
+                self.T("wd/" + l.name, "f16", (l.ntaps * Mpad_d * l.Kd,))
+            self.pack.append(Op("wpack", dict(layer=l.name, M=l.M, cin=l.cin, ntaps=l.ntaps, c0=l.c0, c1_real=l.c1_real,
+                                              Mpad_f=l.Mpad_f, Ktot=l.Ktot, Mpad_d=Mpad_d, Kd=l.Kd, need_d=need_d)))
+        if not self.train:
+            return
+
+        # ---------------- backward ----------------
+        b = self.bwd
+        rt3 = [(-dy, -dx) for dy, dx in t3]   # data gradient reads dZ at (y - dy, x - dx) with the same tap index
+        self.T("g32", "f32", (B, self.Cout, H, W))       # d mean(LOSS) / d net_out, written by the loss kernels
+        self.T("gmax", "u32", (4,))
+        self.T("scale", "f32", (4,))
+        gz = self.act("gz", B, H, W, 16)
+        b.append(Op("grad_pack", dict(g=self.prefix + "g32", dst=View(gz), N=B, C=self.Cout, H=H, W=W, cpad=16)))
+
+        def dgrad(layer, src, csrc, n, h, w, taps, M, dst, mask=None, add=None):
+            self._conv(b, L[layer], "dgrad", View(src), csrc, 0, None, 0, n, h, w, taps, M, dst=dst, bias=False, act=False,
+                       mask=mask, add=add)
+
+        # output_block.4 : 96 -> Cout
+        lo4 = L["output_block.4"]
+        self._wgrad(lo4, View(gz), 16, View(nb), 96, 0, None, 0, 96, B, H, W, TAPS_1x1)
+        g_nb = self.act("g_nb", B, H, W, 96)
+        dgrad("output_block.4", gz, 16, B, H, W, TAPS_1x1, 96, View(g_nb), mask=View(nb))
+        # output_block.2 : nin -> 96
+        lo2 = L["output_block.2"]
+        for ci in range(0, nin, 96):
+            self._wgrad(lo2, View(g_nb), 96, View(na, ci), 96, 0, None, 0, 96, B, H, W, TAPS_1x1, c_off=ci, with_bias=(ci == 0))
+        g_na = self.act("g_na", B, H, W, nin)
+        dgrad("output_block.2", g_nb, 96, B, H, W, TAPS_1x1, nin, View(g_na), mask=View(na))
+        # output_block.0 : nin -> nin
+        lo0 = L["output_block.0"]
+        for mi in range(0, nin, 96):
+            for ci in range(0, nin, 96):
+                self._wgrad(lo0, View(g_na, mi), 96, View(head_in, ci), 96, 0, None, 0, 96, B, H, W, TAPS_1x1,
+                            m_off=mi, c_off=ci, with_bias=(ci == 0))
+        g_d1b = self.act("g_d1b", N, H, W, 96)
+        if bs:
+            g_u = self.act("g_u", B, H, W, 384)
+            dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, View(g_u))
+            b.append(Op("unrot_bwd", dict(src=View(g_u), dst=View(g_d1b), mask=View(d1b), B=B, P=H, C=96)))
+        else:
+            dgrad("output_block.0", g_na, 96, B, H, W, TAPS_1x1, 96, View(g_d1b), mask=View(d1b))
+
+        def dec_bwd(la, lb, ta, tb, g_tb, up_src, c_up, skip, c_skip, c_skip_real, h, w, tag, need_skip_grad=True):
+            """backward of conv_b(conv_a(cat(up(up_src), skip))); returns (g_up_src, view of the skip gradient)."""
+            self._wgrad(L[lb], View(g_tb), 96, View(ta), 96, 0, None, 0, 96, N, h, w, t3)
+            g_ta = self.act("g_" + tag + "a", N, h, w, 96)
+            dgrad(lb, g_tb, 96, N, h, w, rt3, 96, View(g_ta), mask=View(ta))
+            if c_up + c_skip <= 96:
+                self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, View(skip), c_skip, c_up + c_skip_real, N, h, w, t3)
+            else:
+                self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, None, 0, c_up, N, h, w, t3, c_off=0, with_bias=True)
+                self._wgrad(L[la], View(g_ta), 96, None, 0, 0, View(skip), c_skip, c_skip_real, N, h, w, t3, c_off=c_up, with_bias=False)
+            Mx = c_up + (c_skip if need_skip_grad else 0)
+            dxs = self.act("dxs_" + tag, N, h, w, Mx)
+            dgrad(la, g_ta, 96, N, h, w, rt3, Mx, View(dxs))
+            g_up = self.act("g_up_" + tag, N, h // 2, w // 2, c_up)
+            b.append(Op("upsum_bwd", dict(src=View(dxs), mask=View(up_src), dst=View(g_up), N=N, H=h // 2, W=w // 2, C=c_up)))
+            return g_up, (View(dxs, c_up) if need_skip_grad else None)
+
+        g_d2b, _ = dec_bwd("decode_block_1.0", "decode_block_1.2", d1a, d1b, g_d1b, d2b, 96, x16, 16, C, H, W, "d1", need_skip_grad=False)
+        g_d3b, sk_p1 = dec_bwd("decode_block_2.0", "decode_block_2.2", d2a, d2b, g_d2b, d3b, 96, p1, 48, 48, H // 2, W // 2, "d2")
+        g_d4b, sk_p2 = dec_bwd("decode_block_3.0", "decode_block_3.2", d3a, d3b, g_d3b, d4b, 96, p2, 48, 48, H // 4, W // 4, "d3")
+        g_d5b, sk_p3 = dec_bwd("decode_block_4.0", "decode_block_4.2", d4a, d4b, g_d4b, d5b, 96, p3, 48, 48, H // 8, W // 8, "d4")
+        g_e6, sk_p4 = dec_bwd("decode_block_5.0", "decode_block_5.2", d5a, d5b, g_d5b, e6, 48, p4, 48, 48, H // 16, W // 16, "d5")
+
+        def enc_bwd(lname, g_out, src, h, w, tag, skip_add, act_prev):
+            """backward of conv(pool(act_prev)): wgrad, then data gradient w.r.t. `src` (= pooled tensor), plus the
+            decoder's skip gradient, routed through the max-pool to the pre-activation of the previous conv."""
+            self._wgrad(L[lname], View(g_out), 48, View(src), 48, 0, None, 0, 48, N, h, w, t3)
+            g_p = self.act("g_p_" + tag, N, h, w, 48)
+            dgrad(lname, g_out, 48, N, h, w, rt3, 48, View(g_p), add=skip_add)
+            g_prev = self.act("g_e_" + tag, N, 2 * h, 2 * w, 48)
+            b.append(Op("pool_bwd", dict(act=View(act_prev), dpool=View(g_p), dz=View(g_prev), N=N, H=2 * h, W=2 * w, C=48, shifted=int(bs))))
+            return g_prev
+
+        g_e5 = enc_bwd("encode_block_6.0", g_e6, p5, H // 32, W // 32, "6", None, e5)
+        g_e4 = enc_bwd("encode_block_5.0", g_e5, p4, H // 16, W // 16, "5", sk_p4, e4)
+        g_e3 = enc_bwd("encode_block_4.0", g_e4, p3, H // 8, W // 8, "4", sk_p3, e3)
+        g_e2 = enc_bwd("encode_block_3.0", g_e3, p2, H // 4, W // 4, "3", sk_p2, e2)
+        g_e1 = enc_bwd("encode_block_2.0", g_e2, p1, H // 2, W // 2, "2", sk_p1, e1)
+        # encode_block_1.2 (e0 -> e1) and encode_block_1.0 (x16 -> e0)
+        self._wgrad(L["encode_block_1.2"], View(g_e1), 48, View(e0), 48, 0, None, 0, 48, N, H, W, t3)
+        g_e0 = self.act("g_e0", N, H, W, 48)
+        dgrad("encode_block_1.2", g_e1, 48, N, H, W, rt3, 48, View(g_e0), mask=View(e0))
+        self._wgrad(L["encode_block_1.0"], View(g_e0), 48, None, 0, 0, View(x16), 16, C, N, H, W, t3)
+        # shared scratch for the weight-gradient slabs
+        self.T("slab", "f32", (self.max_slab,))
+        self.T("bslab", "f32", (self.max_bslab,))

@@ -1,0 +1,158 @@
+"""ctypes binding of libssdn_hip.so (C-ABI declared in include/ssdn_hip.h -- the struct mirrors below follow that
+header field by field; tests/test_abi.py checks sizes and that every declared symbol is exported).
+
+The product path has NO CPU fallback: if the shared library is missing, `load()` raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libssdn_hip.so")
+MAX_TAPS = 9
+
+# op type codes (enum ssdn_op_type)
+OP = dict(pack_input=1, conv=2, pool_fwd=3, pool_bwd=4, upsum_bwd=5, unrot_fwd=6, unrot_bwd=7, wgrad=8, wreduce=9,
+          wpack=10, grad_pack=11, head_ssdn=12, head_final=13, spatial_mean=14, mse=15, mask_mse=16, adam=17,
+          sqerr=18, zero=19)
+
+i32, f32, vp = C.c_int32, C.c_float, C.c_void_p
+
+
+class View(C.Structure):
+    _fields_ = [("p", vp), ("cs", i32), ("co", i32)]
+
+
+class OpRec(C.Structure):
+    _fields_ = [("type", i32), ("_pad", i32), ("args", vp)]
+
+
+class PackInputArgs(C.Structure):
+    _fields_ = [("src", vp), ("dst", View), ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("R", i32), ("cpad", i32)]
+
+
+class ConvArgs(C.Structure):
+    _fields_ = [("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32), ("H", i32), ("W", i32),
+                ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("w", vp), ("M", i32), ("Mpad", i32),
+                ("Ktot", i32), ("bias", vp), ("act", i32), ("mask", View), ("add", View), ("dst", View), ("dst32", vp),
+                ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32)]
+
+
+class PoolArgs(C.Structure):
+    _fields_ = [("act", View), ("pooled", View), ("dpool", View), ("dz", View), ("N", i32), ("H", i32), ("W", i32),
+                ("C", i32), ("shifted", i32)]
+
+
+class UpsumArgs(C.Structure):
+    _fields_ = [("src", View), ("mask", View), ("dst", View), ("N", i32), ("H", i32), ("W", i32), ("C", i32)]
+
+
+class UnrotArgs(C.Structure):
+    _fields_ = [("src", View), ("dst", View), ("mask", View), ("B", i32), ("P", i32), ("C", i32)]
+
+
+class WgradArgs(C.Structure):
+    _fields_ = [("dz", View), ("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32),
+                ("H", i32), ("W", i32), ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("M", i32),
+                ("Mpad", i32), ("Ktot", i32), ("Kpad", i32), ("slab", vp), ("bslab", vp), ("nslabs", i32), ("ltw", i32),
+                ("lth", i32), ("ltn", i32)]
+
+
+class WreduceArgs(C.Structure):
+    _fields_ = [("slab", vp), ("bslab", vp), ("nslabs", i32), ("ntaps", i32), ("M", i32), ("Mpad", i32), ("Kpad", i32),
+                ("cin", i32), ("cin_full", i32), ("m_off", i32), ("c_off", i32), ("gw", vp), ("gb", vp), ("inv_scale", vp)]
+
+
+class WpackArgs(C.Structure):
+    _fields_ = [("w", vp), ("wf", vp), ("wd", vp), ("M", i32), ("cin", i32), ("ntaps", i32), ("c0", i32), ("c1_real", i32),
+                ("Mpad_f", i32), ("Ktot", i32), ("Mpad_d", i32), ("Kd", i32)]
+
+
+class GradPackArgs(C.Structure):
+    _fields_ = [("g", vp), ("dst", View), ("N", i32), ("C", i32), ("H", i32), ("W", i32), ("cpad", i32), ("gmax", vp),
+                ("scale_out", vp)]
+
+
+class HeadArgs(C.Structure):
+    _fields_ = [("net_out", vp), ("noisy", vp), ("noise_param", vp), ("est_raw", vp), ("B", i32), ("C", i32), ("H", i32),
+                ("W", i32), ("style", i32), ("mode", i32), ("want_grad", i32), ("mu", vp), ("pme", vp), ("model_std", vp),
+                ("noise_std", vp), ("g_net_out", vp), ("partial", vp), ("nchunks", i32), ("gmax", vp)]
+
+
+class HeadFinalArgs(C.Structure):
+    _fields_ = [("partial", vp), ("B", i32), ("nchunks", i32), ("H", i32), ("W", i32), ("mode", i32), ("loss", vp),
+                ("g_est", vp), ("g_sigma_out", vp), ("gmax2", vp)]
+
+
+class SpatialMeanArgs(C.Structure):
+    _fields_ = [("src", vp), ("dst", vp), ("B", i32), ("HW", i32)]
+
+
+class MseArgs(C.Structure):
+    _fields_ = [("out", vp), ("ref", vp), ("coords", vp), ("ncoords", i32), ("B", i32), ("C", i32), ("H", i32), ("W", i32),
+                ("loss", vp), ("g", vp), ("gmax", vp)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("p", vp), ("g", vp), ("m", vp), ("v", vp), ("n", C.c_int64), ("lr", f32), ("b1", f32), ("b2", f32),
+                ("eps", f32), ("bc1", f32), ("bc2", f32), ("gscale", f32)]
+
+
+class SqerrArgs(C.Structure):
+    _fields_ = [("a", vp), ("b", vp), ("dst", vp), ("B", i32), ("n", i32)]
+
+
+class ZeroArgs(C.Structure):
+    _fields_ = [("p", vp), ("bytes", C.c_int64)]
+
+
+ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, pool_bwd=PoolArgs, upsum_bwd=UpsumArgs,
+                 unrot_fwd=UnrotArgs, unrot_bwd=UnrotArgs, wgrad=WgradArgs, wreduce=WreduceArgs, wpack=WpackArgs,
+                 grad_pack=GradPackArgs, head_ssdn=HeadArgs, head_final=HeadFinalArgs, spatial_mean=SpatialMeanArgs,
+                 mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs)
+
+# every symbol include/ssdn_hip.h declares
+SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
+           "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size"]
+
+_lib = None
+
+
+class SsdnHipError(RuntimeError):
+    pass
+
+
+def load() -> C.CDLL:
+    """Load libssdn_hip.so or fail loudly -- there is no fallback path."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise SsdnHipError("libssdn_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the ssdn hot path has no CPU fallback)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.ssdn_run_ops.argtypes = [C.POINTER(OpRec), C.c_int, vp]
+    lib.ssdn_run_ops.restype = C.c_int
+    lib.ssdn_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
+    lib.ssdn_conv_lds_bytes.restype = C.c_int
+    lib.ssdn_wgrad_lds_bytes.argtypes = [C.POINTER(WgradArgs)]
+    lib.ssdn_wgrad_lds_bytes.restype = C.c_int
+    lib.ssdn_abi_version.restype = C.c_int
+    lib.ssdn_last_error.restype = C.c_char_p
+    lib.ssdn_device_cus.restype = C.c_int
+    lib.ssdn_probe_mfma.argtypes = [vp, vp, vp, vp]
+    lib.ssdn_probe_mfma.restype = C.c_int
+    lib.ssdn_probe_tr16.argtypes = [vp, C.c_int, vp, vp, vp]
+    lib.ssdn_probe_tr16.restype = C.c_int
+    lib.ssdn_struct_size.argtypes = [C.c_int]
+    lib.ssdn_struct_size.restype = C.c_int
+    if lib.ssdn_abi_version() != 1:
+        raise SsdnHipError("libssdn_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise SsdnHipError(load().ssdn_last_error().decode())

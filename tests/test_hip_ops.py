@@ -1,0 +1,278 @@
+"""GPU parity tests, called through the C-ABI (libssdn_hip.so):
+
+* hardware probes pin the MFMA / LDS-transpose lane maps the kernels are written against;
+* every planned op of a whole forward+backward is checked IN ISOLATION ("teacher forcing"): its inputs are uploaded from
+  the CPU interpreter (oracle/interp.py, fp16-storage emulation), the single op runs on the device, and its output must
+  match the interpreter's to fp16 rounding -- so one wrong kernel cannot hide behind, or be blamed for, another;
+* end-to-end forward / parameter gradients are compared with the fp32 oracle (oracle/restate.py) and with the golden
+  vectors generated from the reference (tests/golden).
+Tolerances are written next to each assertion.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import restate as R
+from interp import Interp
+from test_lowering_cpu import flat_params
+
+pytestmark = pytest.mark.gpu
+
+OUTDIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------------------
+# probes
+# ------------------------------------------------------------------------------------------------------------
+def test_probe_mfma_layout():
+    """v_mfma_f32_32x32x16_f16: A[i][k] lane = i + 32*(k//8), B[k][j] lane = j + 32*(k//8), D[i][j] in lane j + 32*((i//4)%2),
+    register 4*(i//8) + i%4.  Asymmetric operands so a transposed result cannot pass."""
+    import ctypes as C
+    from ssdn.hip import lib as L
+    lib = L.load()
+    rng = np.random.RandomState(0)
+    A = rng.randint(-3, 4, size=(32, 16)).astype(np.float32)
+    Bm = rng.randint(-3, 4, size=(16, 32)).astype(np.float32)
+    a_frag = np.zeros((64, 8), np.float16)
+    b_frag = np.zeros((64, 8), np.float16)
+    for lane in range(64):
+        for e in range(8):
+            a_frag[lane, e] = A[lane & 31, (lane >> 5) * 8 + e]
+            b_frag[lane, e] = Bm[(lane >> 5) * 8 + e, lane & 31]
+    da, db = torch.from_numpy(a_frag).to(dev()), torch.from_numpy(b_frag).to(dev())
+    dd = torch.zeros(64, 16, device=dev())
+    L.check(lib.ssdn_probe_mfma(C.c_void_p(da.data_ptr()), C.c_void_p(db.data_ptr()), C.c_void_p(dd.data_ptr()), None))
+    torch.cuda.synchronize()
+    d = dd.cpu().numpy()
+    D = A @ Bm
+    got = np.zeros((32, 32), np.float32)
+    for lane in range(64):
+        for r in range(16):
+            got[8 * (r >> 2) + 4 * (lane >> 5) + (r & 3), lane & 31] = d[lane, r]
+    np.testing.assert_array_equal(got, D)
+
+
+def test_probe_tr16_mapping():
+    """ds_read_b64_tr_b16: in each 16-lane group lane i supplies row i>>2, column chunk i&3 of a 4x16 matrix and receives
+    column i.  The raw result is dumped to gpurun_out/tr16_probe.txt for diagnosis."""
+    import ctypes as C
+    from ssdn.hip import lib as L
+    lib = L.load()
+    # LDS image: 64 rows x 16 halves (32 B per row); value = row*16 + col
+    img = (np.arange(64 * 16).reshape(64, 16)).astype(np.float16)
+    addr = np.zeros(64, np.int32)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        row = g * 4 + (i >> 2)
+        addr[lane] = row * 32 + (i & 3) * 8
+    dimg = torch.from_numpy(img).to(dev())
+    daddr = torch.from_numpy(addr).to(dev())
+    dout = torch.zeros(64, 4, dtype=torch.float16, device=dev())
+    L.check(lib.ssdn_probe_tr16(C.c_void_p(dimg.data_ptr()), img.nbytes, C.c_void_p(daddr.data_ptr()), C.c_void_p(dout.data_ptr()), None))
+    torch.cuda.synchronize()
+    out = dout.cpu().numpy().astype(np.int32)
+    os.makedirs(OUTDIR, exist_ok=True)
+    with open(os.path.join(OUTDIR, "tr16_probe.txt"), "w") as f:
+        for lane in range(64):
+            f.write("lane %2d addr row %2d chunk %d -> %s\n" % (lane, addr[lane] // 32, (addr[lane] % 32) // 8,
+                                                              ["(r%d,c%d)" % (v // 16, v % 16) for v in out[lane]]))
+    exp = np.zeros((64, 4), np.int32)
+    for lane in range(64):
+        g, i = lane >> 4, lane & 15
+        for j in range(4):
+            exp[lane, j] = (g * 4 + j) * 16 + i
+    np.testing.assert_array_equal(out, exp)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# per-op teacher-forced parity of a whole planned forward + backward
+# ------------------------------------------------------------------------------------------------------------
+def _upload(dn, it):
+    for name, t in it.t.items():
+        if name in dn.t:
+            dn.t[name].copy_(t.to(dn.t[name].dtype).reshape(dn.t[name].shape))
+
+
+def _out_of(op):
+    a = op.a
+    if op.type == "conv":
+        return ("f32", a["dst32"], None) if a["dst32"] is not None else ("act", a["dst"], a["M"])
+    if op.type == "pool_fwd":
+        return ("act", a["pooled"], a["C"])
+    if op.type == "pool_bwd":
+        return ("act", a["dz"], a["C"])
+    if op.type in ("upsum_bwd",):
+        return ("act", a["dst"], a["C"])
+    if op.type == "unrot_fwd":
+        return ("act", a["dst"], 4 * a["C"])
+    if op.type == "unrot_bwd":
+        return ("act", a["dst"], a["C"])
+    if op.type in ("pack_input", "grad_pack"):
+        return ("act", a["dst"], a["cpad"])
+    return None
+
+
+CASES = [(3, 9, True, 2, 32), (1, 2, True, 1, 32), (3, 3, False, 2, 32), (3, 9, True, 1, 64), (3, 1, False, 2, 64)]
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P", CASES)
+def test_every_op_teacher_forced(cin, cout, bs, B, P):
+    from ssdn.hip.engine import DeviceNet, OpList, current_stream
+    from ssdn.hip.graph import NetPlan
+    from ssdn.hip import lib as L
+    cus = L.load().ssdn_device_cus()
+    p = R.make_params(cin, cout, bs, seed=7)
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=cus)
+    flat = flat_params(plan, p)
+    it = Interp(plan, flat, fp16=True)
+    it.t["m/in32"] = R.hash_tensor((B, cin, P, P), 91, 0, 1)
+    it.run(plan.pack)
+    it.run(plan.fwd)
+    it.t["m/g32"] = R.hash_tensor((B, cout, P, P), 92, -1, 1) * 1e-3
+    it.run(plan.bwd)
+
+    dparams = flat.to(dev())
+    dgrads = torch.zeros_like(dparams)
+    dn = DeviceNet(plan, dev(), dparams, dgrads)
+    dn.t["m/gmax"][0] = int(np.float32(it.t["m/g32"].abs().max()).view(np.int32))
+    dn.pack.run(current_stream())
+    torch.cuda.synchronize()
+    failures = []
+    # packed weights first
+    for l in plan.layers:
+        for kind in ("wf/", "wd/"):
+            name = "m/" + kind + l.name
+            if name in it.t:
+                got = dn.t[name].float().cpu().reshape(it.t[name].shape)
+                if not torch.equal(got, it.t[name]):
+                    failures.append("%s: packed weights differ (max %g)" % (name, float((got - it.t[name]).abs().max())))
+    _upload(dn, it)
+    ops = plan.fwd + plan.bwd
+    i = 0
+    while i < len(ops):
+        op = ops[i]
+        if op.type == "wgrad":
+            pair = [dn._mat(op), dn._mat(ops[i + 1])]
+            a2 = ops[i + 1].a
+            l = next(x for x in plan.layers if x.name == a2["layer"])
+            dgrads.fill_(float("nan"))
+            dn.t["m/scale"][0] = it.scale
+            dn.t["m/scale"][1] = 1.0 / it.scale
+            OpList(pair).run(current_stream())
+            torch.cuda.synchronize()
+            gw = dgrads[l.w_off:l.w_off + l.M * l.cin * l.ntaps].cpu().reshape(l.M, l.cin, l.ntaps)
+            rw = it.grads[l.w_off:l.w_off + l.M * l.cin * l.ntaps].reshape(l.M, l.cin, l.ntaps)
+            sl = (slice(a2["m_off"], a2["m_off"] + a2["M"]), slice(a2["c_off"], a2["c_off"] + a2["cin"]))
+            g, r = gw[sl], rw[sl]
+            # fp32 accumulation over up to 2^17 fp16 products in a different order: 1e-3 of the block's scale
+            tol = 1e-3 * float(r.abs().max()) + 1e-12
+            err = float((g - r).abs().max()) if torch.isfinite(g).all() else float("inf")
+            if not err <= tol:
+                failures.append("op %d wgrad %s m_off %d c_off %d: max err %.3e (tol %.3e)" % (i, l.name, a2["m_off"], a2["c_off"], err, tol))
+            if a2["with_bias"]:
+                gb = dgrads[l.b_off + a2["m_off"]: l.b_off + a2["m_off"] + a2["M"]].cpu()
+                rb = it.grads[l.b_off + a2["m_off"]: l.b_off + a2["m_off"] + a2["M"]]
+                tolb = 1e-3 * float(rb.abs().max()) + 1e-12
+                errb = float((gb - rb).abs().max()) if torch.isfinite(gb).all() else float("inf")
+                if not errb <= tolb:
+                    failures.append("op %d bias-grad %s: max err %.3e (tol %.3e)" % (i, l.name, errb, tolb))
+            i += 2
+            continue
+        kind, dst, ch = _out_of(op)
+        rec = dn._mat(op)
+        if kind == "f32":
+            dn.t[dst].fill_(float("nan"))
+        else:
+            dn.t[dst.t][..., dst.co:dst.co + ch] = float("nan")
+        OpList([rec]).run(current_stream())
+        torch.cuda.synchronize()
+        if kind == "f32":
+            got, ref = dn.t[dst].cpu(), it.t[dst]
+        else:
+            got, ref = dn.t[dst.t][..., dst.co:dst.co + ch].float().cpu(), it.t[dst.t][..., dst.co:dst.co + ch]
+        # one fp16 ulp (2^-10 relative) + accumulation-order noise
+        tol = 2e-3 * ref.abs() + 2e-3 * float(ref.abs().max()) * 1e-2 + 1e-7
+        bad = ~((got - ref).abs() <= tol)
+        if bad.any():
+            idx = bad.nonzero()[0].tolist()
+            failures.append("op %d %s %s: %d/%d elements off, max err %.3e, first at %s got %g want %g" % (
+                i, op.type, op.a.get("layer", ""), int(bad.sum()), bad.numel(),
+                float(torch.nan_to_num((got - ref).abs(), nan=9e9).max()), idx, float(got[tuple(idx)]), float(ref[tuple(idx)])))
+        # restore the forced value
+        if kind == "f32":
+            dn.t[dst].copy_(ref)
+        else:
+            dn.t[dst.t][..., dst.co:dst.co + ch] = ref.to(dev()).half()
+        i += 1
+    os.makedirs(OUTDIR, exist_ok=True)
+    with open(os.path.join(OUTDIR, "teacher_forced_%d_%d_%d_%d_%d.txt" % (cin, cout, int(bs), B, P)), "w") as f:
+        f.write("\n".join(failures) if failures else "all %d ops OK\n" % len(ops))
+    assert not failures, "\n".join(failures[:40])
+
+
+# ------------------------------------------------------------------------------------------------------------
+# end-to-end network forward / backward vs the fp32 oracle and the reference's golden vectors
+# ------------------------------------------------------------------------------------------------------------
+def _rel(a, b):
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("tag,cin,cout,bs", [("bs_rgb", 3, 9, True), ("bs_mono", 1, 2, True), ("plain_rgb", 3, 3, False), ("sigma", 3, 1, False)])
+def test_net_forward_vs_reference_golden(golden_dir, tag, cin, cout, bs):
+    """fp16 storage / fp32 accumulation against the reference's fp32 output: relative L2 error <= 5e-3."""
+    from ssdn.hip.engine import DeviceNet, current_stream
+    from ssdn.hip.graph import NetPlan
+    from ssdn.hip import lib as L
+    g = np.load(os.path.join(golden_dir, "g_net_%s.npz" % tag))
+    plan = NetPlan("m/", cin, cout, bs, 2, 32, 32, cus=L.load().ssdn_device_cus(), train=False)
+    flat = flat_params(plan, R.make_params(cin, cout, bs, seed=3)).to(dev())
+    dn = DeviceNet(plan, dev(), flat, None)
+    dn.t["m/in32"].copy_(R.hash_tensor((2, cin, 32, 32), 31, 0, 1))
+    dn.pack.run(current_stream())
+    dn.fwd.run(current_stream())
+    torch.cuda.synchronize()
+    out = dn.t["m/out32"].cpu()
+    assert _rel(out, torch.from_numpy(g["out"])) <= 5e-3
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P", [(3, 9, True, 2, 32), (3, 3, False, 2, 64)])
+def test_net_backward_vs_oracle(cin, cout, bs, B, P):
+    """parameter gradients of the whole HIP backward vs autograd of the fp32 oracle: per-tensor relative L2 <= 3e-2,
+    cosine >= 0.999 (fp16 activations + LeakyReLU/max-pool branch flips near zero set the floor)."""
+    from ssdn.hip.engine import DeviceNet, current_stream
+    from ssdn.hip.graph import NetPlan
+    from ssdn.hip import lib as L
+    p = R.make_params(cin, cout, bs, seed=7)
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=L.load().ssdn_device_cus())
+    flat = flat_params(plan, p).to(dev())
+    grads = torch.zeros_like(flat)
+    dn = DeviceNet(plan, dev(), flat, grads)
+    x = R.hash_tensor((B, cin, P, P), 91, 0, 1)
+    g = R.hash_tensor((B, cout, P, P), 92, -1, 1) * 1e-3
+    dn.t["m/in32"].copy_(x)
+    dn.pack.run(current_stream())
+    dn.fwd.run(current_stream())
+    dn.t["m/g32"].copy_(g)
+    dn.t["m/gmax"][0] = int(np.float32(g.abs().max()).view(np.int32))
+    dn.bwd.run(current_stream())
+    torch.cuda.synchronize()
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = R.net_forward(leaves, x, bs)
+    (ref * g).sum().backward()
+    assert _rel(dn.t["m/out32"].cpu(), ref.detach()) <= 5e-3
+    gh = grads.cpu()
+    bad = []
+    for l in plan.layers:
+        for nm, sl, rg in (("w", slice(l.w_off, l.w_off + l.M * l.cin * l.ntaps), leaves[l.name + ".weight"].grad.reshape(-1)),
+                           ("b", slice(l.b_off, l.b_off + l.M), leaves[l.name + ".bias"].grad)):
+            a = gh[sl]
+            cos = float((a * rg).sum() / (a.norm() * rg.norm() + 1e-30))
+            if not (_rel(a, rg) <= 3e-2 and cos >= 0.999):
+                bad.append("%s.%s rel %.3e cos %.5f" % (l.name, nm, _rel(a, rg), cos))
+    assert not bad, "\n".join(bad)

@@ -1,0 +1,70 @@
+"""CPU check of the LOWERING (ssdn.hip.graph.NetPlan) with the test-only interpreter (oracle/interp.py):
+the planned op list, executed naively in fp32, must reproduce the oracle's forward and autograd gradients."""
+import numpy as np
+import pytest
+import torch
+
+import restate as R
+from interp import Interp
+from ssdn.hip.graph import NetPlan
+
+
+def flat_params(plan, p):
+    flat = torch.zeros(plan.nparams, dtype=next(iter(p.values())).dtype)
+    for l in plan.layers:
+        flat[l.w_off:l.w_off + l.M * l.cin * l.ntaps] = p[l.name + ".weight"].reshape(-1)
+        flat[l.b_off:l.b_off + l.M] = p[l.name + ".bias"]
+    return flat
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P", [(3, 9, True, 2, 32), (1, 2, True, 1, 32), (3, 3, False, 2, 32), (3, 1, False, 1, 64)])
+def test_forward_backward_lowering(cin, cout, bs, B, P):
+    """float64 on both sides: in fp32 a handful of activations within 1e-7 of zero flip the LeakyReLU branch between two
+    summation orders, which hides real bugs behind a 1e-3 noise floor; in fp64 the lowering must agree to ~1e-12."""
+    torch.set_default_dtype(torch.float64)
+    try:
+        _check_lowering(cin, cout, bs, B, P)
+    finally:
+        torch.set_default_dtype(torch.float32)
+
+
+def _check_lowering(cin, cout, bs, B, P):
+    p = {k: v.double() for k, v in R.make_params(cin, cout, bs, seed=7).items()}
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=8)
+    it = Interp(plan, flat_params(plan, p), fp16=False)
+    x = R.hash_tensor((B, cin, P, P), 91, 0, 1).double()
+    it.t["m/in32"] = x.clone()
+    it.run(plan.pack)
+    it.run(plan.fwd)
+    leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+    ref = R.net_forward(leaves, x, bs)
+    np.testing.assert_allclose(it.t["m/out32"].numpy(), ref.detach().numpy(), rtol=1e-9, atol=1e-11)
+    # backward: arbitrary upstream gradient
+    g = R.hash_tensor((B, cout, P, P), 92, -1, 1).double() * 1e-3
+    (ref * g).sum().backward()
+    it.t["m/g32"] = g.clone()
+    it.run(plan.bwd)
+    for l in plan.layers:
+        gw = it.grads[l.w_off:l.w_off + l.M * l.cin * l.ntaps].reshape(l.M, l.cin, l.k, l.k)
+        gb = it.grads[l.b_off:l.b_off + l.M]
+        rw, rb = leaves[l.name + ".weight"].grad, leaves[l.name + ".bias"].grad
+        sc = float(rw.abs().max()) + 1e-12
+        np.testing.assert_allclose(gw.numpy(), rw.numpy(), rtol=1e-8, atol=1e-10 * sc, err_msg=l.name)
+        np.testing.assert_allclose(gb.numpy(), rb.numpy(), rtol=1e-8, atol=1e-10 * (float(rb.abs().max()) + 1e-12), err_msg=l.name)
+
+
+def test_plan_tilings_fit_lds():
+    """every conv / wgrad tiling of the BASELINE configurations fits the 160 KiB LDS of a CU"""
+    from ssdn.hip.graph import LDS_LIMIT
+    for (cin, cout, bs, B, P) in [(3, 9, True, 32, 64), (3, 9, True, 16, 128), (3, 3, False, 32, 64), (1, 1, False, 4, 32),
+                                  (3, 9, True, 2, 768), (3, 9, True, 2, 512)]:
+        plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=256, train=P <= 128)
+        for op in plan.fwd + plan.bwd:
+            a = op.a
+            if op.type == "conv":
+                padT = max(0, -min(t[0] for t in a["taps"])); padB = max(0, max(t[0] for t in a["taps"]))
+                padL = max(0, -min(t[1] for t in a["taps"])); padR = max(0, max(t[1] for t in a["taps"]))
+                NP = (1 << a["ltn"]) * ((1 << a["lth"]) + padT + padB) * ((1 << a["ltw"]) + padL + padR)
+                lds = NP * (a["kc"] * 2 + 16) + min(3, a["Mpad"] // 32) * 32 * (a["kc"] * 2 + 16)
+                assert lds <= LDS_LIMIT
+                assert a["ltw"] + a["lth"] + a["ltn"] <= 8
