@@ -312,6 +312,18 @@ const char* ssdn_last_error(void);
 /* number of compute units of the current device (used to size persistent grids) */
 int ssdn_device_cus(void);
 
+/* In-stream profiler used by bench.py's roofline leg: when enabled for a kernel family, every launch of that family is
+ * bracketed by a hipEvent pair ON THE LAUNCH STREAM; ssdn_profile_read() synchronises, returns the summed device time,
+ * the number of launches and the ALGORITHMIC flops / bytes those launches stood for (DESIGN.md gives the formulas),
+ * and resets the counters.  max_launches = 0 disables. */
+#define SSDN_PROF_CONV_MT3 0
+#define SSDN_PROF_CONV_MT2 1
+#define SSDN_PROF_CONV_MT1 2
+#define SSDN_PROF_WGRAD 3
+#define SSDN_PROF_KINDS 4
+int ssdn_profile_enable(int kind, int max_launches);
+int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* flops, double* bytes);
+
 /* Hardware probes used by the test-suite (tests/test_hip_probe.py): raw lane mapping of
  * v_mfma_f32_32x32x16_f16 and ds_read_b64_tr_b16 on this device.  out: device buffers. */
 int ssdn_probe_mfma(const void* a_frag, const void* b_frag, float* d_out, void* stream);

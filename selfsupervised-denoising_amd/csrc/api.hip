@@ -14,6 +14,30 @@ int ssdn_set_error(const char* fmt, ...) {
     return -1;
 }
 
+// ---- in-stream kernel profiler: HIP events around every launch of a chosen kernel family (bench.py's roofline leg) ----
+#include <vector>
+struct ProfSlot {
+    bool on = false;
+    std::vector<hipEvent_t> ev;
+    size_t used = 0;
+    double flops = 0.0, bytes = 0.0;
+};
+static ProfSlot g_prof[SSDN_PROF_KINDS];
+
+void prof_begin(int id, hipStream_t s) {
+    ProfSlot& p = g_prof[id];
+    if (!p.on || p.used + 2 > p.ev.size()) return;
+    (void)hipEventRecord(p.ev[p.used], s);
+}
+void prof_end(int id, hipStream_t s, double flops, double bytes) {
+    ProfSlot& p = g_prof[id];
+    if (!p.on || p.used + 2 > p.ev.size()) return;
+    (void)hipEventRecord(p.ev[p.used + 1], s);
+    p.used += 2;
+    p.flops += flops;
+    p.bytes += bytes;
+}
+
 __global__ void k_zero(uint4* p, long long n16) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     for (; i < n16; i += (long long)gridDim.x * blockDim.x) p[i] = make_uint4(0, 0, 0, 0);
@@ -54,6 +78,41 @@ int ssdn_struct_size(int op_type) {
         case SSDN_OP_ZERO: return (int)sizeof(ssdn_zero_args);
         default: return -1;
     }
+}
+
+int ssdn_profile_enable(int kind, int max_launches) {
+    if (kind < 0 || kind >= SSDN_PROF_KINDS) return ssdn_set_error("profile: bad kernel kind %d", kind);
+    ProfSlot& p = g_prof[kind];
+    for (hipEvent_t e : p.ev) (void)hipEventDestroy(e);
+    p.ev.clear();
+    p.used = 0;
+    p.flops = p.bytes = 0.0;
+    p.on = max_launches > 0;
+    for (int i = 0; i < 2 * max_launches; ++i) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) return ssdn_set_error("profile: hipEventCreate failed");
+        p.ev.push_back(e);
+    }
+    return 0;
+}
+
+int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* flops, double* bytes) {
+    if (kind < 0 || kind >= SSDN_PROF_KINDS) return ssdn_set_error("profile: bad kernel kind %d", kind);
+    ProfSlot& p = g_prof[kind];
+    double ms = 0.0;
+    for (size_t i = 0; i + 1 < p.used; i += 2) {
+        if (hipEventSynchronize(p.ev[i + 1]) != hipSuccess) return ssdn_set_error("profile: hipEventSynchronize failed");
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, p.ev[i], p.ev[i + 1]) != hipSuccess) return ssdn_set_error("profile: hipEventElapsedTime failed");
+        ms += t;
+    }
+    *total_ms = ms;
+    *launches = (long long)(p.used / 2);
+    *flops = p.flops;
+    *bytes = p.bytes;
+    p.used = 0;
+    p.flops = p.bytes = 0.0;
+    return 0;
 }
 
 int ssdn_conv_lds_bytes(const ssdn_conv_args* a) { return conv_lds_bytes(a); }

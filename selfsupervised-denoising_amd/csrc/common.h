@@ -36,6 +36,10 @@ static __device__ __forceinline__ half8 zero_h8() {
     return z;
 }
 
+// in-stream profiler (api.hip)
+void prof_begin(int kind, hipStream_t s);
+void prof_end(int kind, hipStream_t s, double flops, double bytes);
+
 // launchers implemented in the individual .hip files; all return 0 / negative error
 int launch_conv(const ssdn_conv_args* a, hipStream_t s);
 int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s);

@@ -224,7 +224,15 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     for (int by = 0; by < nblk_y; ++by) {
         ConvAux xx = x;
         xx.m_base = x.m_base + by * MT * 32;
+        // algorithmic work of THIS launch: real output channels x real input channels x taps x real pixels
+        int m_real = a->M - xx.m_base;
+        m_real = m_real < 0 ? 0 : (m_real > MT * 32 ? MT * 32 : m_real);
+        double px = (double)a->N * a->H * a->W;
+        double flops = 2.0 * px * m_real * a->Ktot * a->ntaps;
+        double bytes = px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
+        prof_begin(3 - MT, s);
         hipLaunchKernelGGL(k_conv<MT>, dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
+        prof_end(3 - MT, s, flops, bytes);
     }
     return 0;
 }

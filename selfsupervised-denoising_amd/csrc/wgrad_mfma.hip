@@ -235,7 +235,10 @@ static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& 
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad<MT, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    double px = (double)a->N * a->H * a->W;
+    prof_begin(SSDN_PROF_WGRAD, s);
     hipLaunchKernelGGL((k_wgrad<MT, CPW>), dim3(a->nslabs), dim3(WG_THREADS), lds, s, *a, x);
+    prof_end(SSDN_PROF_WGRAD, s, 2.0 * px * a->M * a->Ktot * a->ntaps, px * 2.0 * (a->M + a->Ktot));
     return 0;
 }
 

@@ -1,0 +1,243 @@
+"""`Denoiser` -- network(s) + loss head of one ssdn configuration, MI355X edition.
+
+Drop-in for /root/reference/ssdn/ssdn/denoiser.py:23-412: same constructor (`cfg`, `device`), `run_pipeline`, `forward`,
+`get_model`, `state_dict` / `from_state_dict` (same key layout incl. the DataParallel `module.` prefix and the `_models`
+aliases) and `config_name`.  What differs is everything underneath: the nets' parameters are views
+into ONE flat fp32 device buffer [main net | sigma estimator | learnable sigma scalar]; a forward / loss / backward /
+optimiser step is four calls into libssdn_hip.so (`ssdn.hip.engine.DenoiserEngine`); nn.DataParallel is gone -- data
+parallelism is one process per GPU with an RCCL all-reduce of the flat gradient (`ssdn.hip.dp`).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+import ssdn
+from ssdn.datasets import NoisyDataset
+from ssdn.models import NoiseNetwork
+from ssdn.params import ConfigValue, NoiseValue, Pipeline, PipelineOutput
+
+
+class _ParallelShim(nn.Module):
+    """Occupies the place of nn.DataParallel in the module tree so that checkpoints keep the
+    `models.<id>.module.<param>` key layout (denoiser.py:102-110).  It parallelises nothing."""
+
+    def __init__(self, module: nn.Module):
+        super().__init__()
+        self.module = module
+
+    def forward(self, *a, **k):
+        return self.module(*a, **k)
+
+
+class _LossBridge(torch.autograd.Function):
+    """Lets the reference's training idiom `torch.mean(outputs[LOSS]).backward()` drive the HIP backward pass:
+    the returned LOSS tensor carries this node; its backward runs the planned backward op list and exposes the flat
+    gradient buffer through every parameter's `.grad`."""
+
+    @staticmethod
+    def forward(ctx, anchor: Tensor, denoiser: "Denoiser", loss: Tensor):
+        ctx.denoiser = denoiser
+        return loss.clone()
+
+    @staticmethod
+    def backward(ctx, grad_out: Tensor):
+        d = ctx.denoiser
+        B = grad_out.shape[0]
+        if not torch.allclose(grad_out, torch.full_like(grad_out, 1.0 / B), rtol=1e-5, atol=0):
+            raise NotImplementedError("the fused loss head differentiates mean(LOSS) over the batch (train.py:201); "
+                                      "other reductions of LOSS are not supported")
+        d.backward()
+        return None, None, None
+
+
+class Denoiser(nn.Module):
+    MODEL = "denoiser_model"
+    SIGMA_ESTIMATOR = "sigma_estimation_model"
+    ESTIMATED_SIGMA = "estimated_sigma"
+
+    def __init__(self, cfg: Dict, device: str = None):
+        super().__init__()
+        self.device = torch.device(device) if device else torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.cfg = cfg
+        C = cfg[ConfigValue.IMAGE_CHANNELS]
+        self._pipeline = cfg[ConfigValue.PIPELINE]
+        ssdn_pipe = self._pipeline == Pipeline.SSDN
+        if ssdn_pipe and cfg.get(ConfigValue.DIAGONAL_COVARIANCE):
+            # the reference's diagonal branch raises (`c00.shape()`, denoiser.py:240) and is unreachable from its CLI
+            raise NotImplementedError("DIAGONAL_COVARIANCE is broken in the reference (denoiser.py:240) and not supported")
+        cout = C + (C * (C + 1)) // 2 if ssdn_pipe else C               # means + triangular A (denoiser.py:55-64)
+        self._var = ssdn_pipe and cfg[ConfigValue.NOISE_VALUE] == NoiseValue.UNKNOWN_VARIABLE
+        self._const = ssdn_pipe and cfg[ConfigValue.NOISE_VALUE] == NoiseValue.UNKNOWN_CONSTANT
+        blind = cfg[ConfigValue.BLINDSPOT]
+        from ssdn.hip.graph import net_layers, net_param_count
+        n_main = net_param_count(net_layers(C, cout, blind))
+        n_sig = net_param_count(net_layers(C, 1, False)) if self._var else 0
+        n_tot = n_main + n_sig + (1 if self._const else 0)
+        n_pad = (n_tot + 3) // 4 * 4
+        self._n_main, self._n_sig = n_main, n_sig
+        self.flat = torch.zeros(n_pad, device=self.device)
+        self.flat_grad = torch.zeros(n_pad, device=self.device)
+        self.adam_m = torch.zeros(n_pad, device=self.device)
+        self.adam_v = torch.zeros(n_pad, device=self.device)
+        self.adam_steps = 0
+
+        self.models = nn.ModuleDict()    # "parallelised" handles (reference: nn.DataParallel wrappers)
+        self._models = nn.ModuleDict()   # plain handles to the same modules
+        self._add(Denoiser.MODEL, NoiseNetwork(C, cout, blindspot=blind, device=self.device,
+                                               flat=(self.flat[:n_main], self.flat_grad[:n_main])))
+        if self._var:
+            self._add(Denoiser.SIGMA_ESTIMATOR, NoiseNetwork(C, 1, blindspot=False, zero_output_weights=True, device=self.device,
+                                                            flat=(self.flat[n_main:n_main + n_sig], self.flat_grad[n_main:n_main + n_sig])))
+        self.l_params = nn.ParameterDict()
+        if self._const:
+            self.l_params[Denoiser.ESTIMATED_SIGMA] = nn.Parameter(self.flat[n_main + n_sig:n_main + n_sig + 1].view(1, 1, 1, 1))
+        self._engines: Dict[Tuple, list] = {}
+        self._version = 0
+        self._last_engine = None
+        self._anchor = torch.zeros((), requires_grad=True)
+
+    def _add(self, model_id: str, model: nn.Module):
+        self._models[model_id] = model
+        self.models[model_id] = _ParallelShim(model)
+
+    # ---- reference surface --------------------------------------------------------------------------------------
+    def get_model(self, model_id: str, parallelised: bool = True) -> nn.Module:
+        return (self.models if parallelised else self._models)[model_id]
+
+    def config_name(self) -> str:
+        return ssdn.cfg.config_name(self.cfg)
+
+    def state_dict(self, params_only: bool = False, **kw) -> Dict:
+        sd = super().state_dict(**kw)
+        if not params_only:
+            sd["cfg"] = self.cfg
+        return sd
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        sd = {k: v for k, v in state_dict.items() if k != "cfg"}
+        r = super().load_state_dict(sd, strict=strict, **kw)
+        self.mark_dirty()
+        return r
+
+    @staticmethod
+    def from_state_dict(state_dict: Dict) -> "Denoiser":
+        d = Denoiser(state_dict["cfg"])
+        d.load_state_dict(state_dict, strict=False)
+        return d
+
+    def mark_dirty(self):
+        self._version += 1
+
+    # ---- engines ---------------------------------------------------------------------------------------------------
+    def _engine(self, B: int, H: int, W: int, train: bool, ncoords: int = 64):
+        from ssdn.hip import lib as L
+        from ssdn.hip.engine import DenoiserEngine
+        if self.device.type != "cuda":
+            raise L.SsdnHipError("Denoiser.run_pipeline needs an MI355X: device is %s and the ssdn hot path has no CPU fallback" % self.device)
+        key = (B, H, W, train, ncoords)
+        if key not in self._engines:
+            cfg = self.cfg
+            eng = DenoiserEngine(self._pipeline.value, cfg[ConfigValue.IMAGE_CHANNELS], cfg[ConfigValue.BLINDSPOT],
+                                 cfg.get(ConfigValue.NOISE_STYLE) or "gauss", cfg[ConfigValue.NOISE_VALUE].value if self._pipeline == Pipeline.SSDN else "known",
+                                 B, H, W, self.device, self.flat, self.flat_grad, self.adam_m, self.adam_v,
+                                 self._n_main, self._n_sig, self._const, train=train, ncoords=ncoords)
+            self._engines[key] = [eng, -1]
+        slot = self._engines[key]
+        if slot[1] != self._version:
+            slot[0].repack()
+            slot[1] = self._version
+        return slot[0]
+
+    # ---- pipelines -------------------------------------------------------------------------------------------------
+    def forward(self, data: Tensor) -> Tensor:
+        """Inference (denoiser.py:112-126): denoise a BCHW batch with the configured pipeline."""
+        return self.run_pipeline([data])[PipelineOutput.IMG_DENOISED]
+
+    def run_pipeline(self, data: List, **kwargs) -> Dict:
+        if self._pipeline not in (Pipeline.MSE, Pipeline.SSDN, Pipeline.MASK_MSE):
+            raise NotImplementedError("Unsupported processing pipeline")
+        inp = data[NoisyDataset.INPUT]
+        B, C, H, W = inp.shape
+        ref = data[NoisyDataset.REFERENCE] if len(data) > NoisyDataset.REFERENCE else None
+        meta = data[NoisyDataset.METADATA] if len(data) > NoisyDataset.METADATA else {}
+        MD = NoisyDataset.Metadata
+        coords = meta.get(MD.MASK_COORDS) if isinstance(meta, dict) else None
+        train = self.training and torch.is_grad_enabled()
+        eng = self._engine(B, H, W, train, ncoords=(coords.shape[1] if coords is not None else 64))
+        eng.inp.copy_(inp.to(torch.float32), non_blocking=True)          # device boundary (denoiser.py:143,186)
+        have_loss = True
+        if self._pipeline == Pipeline.SSDN:
+            if self.cfg[ConfigValue.NOISE_VALUE] == NoiseValue.KNOWN:
+                eng.noise_param.copy_(meta[MD.INPUT_NOISE_VALUES].reshape(B).to(torch.float32), non_blocking=True)
+        else:
+            have_loss = ref is not None and (self._pipeline == Pipeline.MSE or coords is not None)
+            if have_loss:
+                eng.ref.copy_(ref.to(torch.float32), non_blocking=True)
+                if self._pipeline == Pipeline.MASK_MSE:
+                    eng.coords.copy_(coords[0].to(torch.int64), non_blocking=True)   # element 0's mask for everyone (n2v_loss.py:12)
+        if have_loss:
+            eng.forward()
+        else:
+            eng.net_forward_only()
+        self._last_engine = eng
+        out = {PipelineOutput.INPUTS: data}
+        net_out = eng.main.tensor("out32")
+        if self._pipeline == Pipeline.SSDN:
+            out[PipelineOutput.IMG_MU] = eng.mu
+            out[PipelineOutput.IMG_DENOISED] = eng.pme
+            gauss = eng.style == "gauss"
+            nstd = eng.noise_std
+            if gauss:
+                nstd = nstd[:1].view(1, 1, 1) if self._const else nstd.view(B, 1, 1)
+            out[PipelineOutput.NOISE_STD_DEV] = nstd
+            out[PipelineOutput.MODEL_STD_DEV] = eng.model_std
+        else:
+            out[PipelineOutput.IMG_DENOISED] = net_out
+        if have_loss:
+            loss = eng.loss
+            out[PipelineOutput.LOSS] = _LossBridge.apply(self._anchor, self, loss) if train else loss
+        return out
+
+    def backward(self):
+        """Run the planned backward pass of the last training-mode run_pipeline; gradients land in `flat_grad` and are
+        visible as `.grad` of every parameter."""
+        eng = self._last_engine
+        if eng is None or not eng.train:
+            raise RuntimeError("backward() needs a preceding training-mode run_pipeline()")
+        eng.backward()
+        self._expose_grads()
+
+    def _expose_grads(self):
+        for net, base in ((self._models[Denoiser.MODEL], 0),) + (((self._models[Denoiser.SIGMA_ESTIMATOR], self._n_main),) if self._var else ()):
+            for l in net.layers:
+                h = net.get_submodule(l.name)
+                h.weight.grad = self.flat_grad[base + l.w_off: base + l.w_off + l.M * l.cin * l.k * l.k].view(l.M, l.cin, l.k, l.k)
+                h.bias.grad = self.flat_grad[base + l.b_off: base + l.b_off + l.M]
+        if self._const:
+            o = self._n_main + self._n_sig
+            self.l_params[Denoiser.ESTIMATED_SIGMA].grad = self.flat_grad[o:o + 1].view(1, 1, 1, 1)
+
+    def optimizer_step(self, lr: float, grad_scale: float = 1.0):
+        """Fused Adam (betas 0.9/0.99, eps 1e-8; train.py:100-107) over the flat buffer + re-pack of the fp16 MFMA shadows."""
+        eng = self._last_engine
+        self.adam_steps += 1
+        eng.adam(lr, self.adam_steps, grad_scale)
+        # shadows of THIS engine are fresh; other cached shapes re-pack lazily
+        self._version += 1
+        for slot in self._engines.values():
+            if slot[0] is eng:
+                slot[1] = self._version
+
+    def train_step(self, data: List, lr: float, allreduce=None) -> Dict:
+        """One whole optimisation step on this GPU: forward + loss + backward (+ gradient all-reduce) + Adam."""
+        out = self.run_pipeline(data)
+        self._last_engine.backward()
+        scale = 1.0
+        if allreduce is not None:
+            scale = allreduce(self.flat_grad)
+        self.optimizer_step(lr, scale)
+        return out

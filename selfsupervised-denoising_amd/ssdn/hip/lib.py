@@ -114,7 +114,9 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
 
 # every symbol include/ssdn_hip.h declares
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
-           "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size"]
+           "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
+           "ssdn_profile_read"]
+PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3)
 
 _lib = None
 
@@ -145,6 +147,10 @@ def load() -> C.CDLL:
     lib.ssdn_probe_mfma.restype = C.c_int
     lib.ssdn_probe_tr16.argtypes = [vp, C.c_int, vp, vp, vp]
     lib.ssdn_probe_tr16.restype = C.c_int
+    lib.ssdn_profile_enable.argtypes = [C.c_int, C.c_int]
+    lib.ssdn_profile_enable.restype = C.c_int
+    lib.ssdn_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    lib.ssdn_profile_read.restype = C.c_int
     lib.ssdn_struct_size.argtypes = [C.c_int]
     lib.ssdn_struct_size.restype = C.c_int
     if lib.ssdn_abi_version() != 1:

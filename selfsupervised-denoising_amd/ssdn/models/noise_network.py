@@ -1,0 +1,150 @@
+"""`NoiseNetwork` -- the (optionally blind-spot) U-Net of the ssdn package, MI355X edition.
+
+Same constructor, `forward`, `blindspot`, `init_weights`, `input_wh_mul` and `state_dict` layout as the reference module
+(/root/reference/ssdn/ssdn/models/noise_network.py:13-238), but it is NOT a stack of torch.nn layers: the module only
+owns the parameters (as views into one flat fp32 buffer, the layout the fused Adam / RCCL all-reduce work on) and
+`forward` executes the planned op list of `ssdn.hip.graph.NetPlan` through libssdn_hip.so.  There is no eager /
+autograd / CPU fallback: without the HIP library or a GPU `forward` raises.
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from ssdn.hip.graph import net_layers, net_param_count
+
+
+class _ConvParams(nn.Module):
+    """Parameter holder standing where the reference has an nn.Conv2d / ShiftConv2d (same key names, OIHW weight)."""
+
+    def __init__(self, weight: Tensor, bias: Tensor):
+        super().__init__()
+        self.weight = nn.Parameter(weight, requires_grad=True)
+        self.bias = nn.Parameter(bias, requires_grad=True)
+
+
+class _Slots(nn.Module):
+    """nn.Sequential-like container whose children keep the reference's numeric names ('0', '2', '4')."""
+
+    def __init__(self, children: Dict[str, nn.Module]):
+        super().__init__()
+        for k, m in children.items():
+            self.add_module(k, m)
+
+
+class NoiseNetwork(nn.Module):
+    def __init__(self, in_channels: int = 3, out_channels: int = 3, blindspot: bool = False,
+                 zero_output_weights: bool = False, device: Optional[torch.device] = None,
+                 flat: Optional[Tuple[Tensor, Optional[Tensor]]] = None):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self._blindspot = blindspot
+        self._zero_output_weights = zero_output_weights
+        self.layers = net_layers(in_channels, out_channels, blindspot)
+        self.nparams = net_param_count(self.layers)
+        if device is None:
+            device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self._device = torch.device(device)
+        if flat is None:
+            flat = (torch.zeros(self.nparams, device=self._device), None)
+        self._flat, self._flat_grad = flat
+        assert self._flat.numel() == self.nparams
+        # parameter views + the reference's module tree (noise_network.py:69-156)
+        holders = OrderedDict()
+        for l in self.layers:
+            w = self._flat[l.w_off:l.w_off + l.M * l.cin * l.k * l.k].view(l.M, l.cin, l.k, l.k)
+            b = self._flat[l.b_off:l.b_off + l.M]
+            holders[l.name] = _ConvParams(w, b)
+        blocks = OrderedDict()
+        for name, h in holders.items():
+            blk, idx = name.split(".")
+            blocks.setdefault(blk, OrderedDict())[idx] = h
+        for blk in ("encode_block_1", "encode_block_2", "encode_block_3", "encode_block_4", "encode_block_5", "encode_block_6",
+                    "decode_block_5", "decode_block_4", "decode_block_3", "decode_block_2", "decode_block_1"):
+            self.add_module(blk, _Slots(blocks[blk]))
+        self.output_conv = blocks["output_block"]["4"]          # alias: ONE parameter under two names (noise_network.py:149-156)
+        self.output_block = _Slots(blocks["output_block"])
+        self._engines: Dict[Tuple[int, int, int], list] = {}   # shape -> [DeviceNet, parameter version its shadows hold]
+        self._version = 0
+        self.init_weights()
+
+    # ---- reference surface ----------------------------------------------------------------------------------
+    @property
+    def blindspot(self) -> bool:
+        return self._blindspot
+
+    @staticmethod
+    def input_wh_mul() -> int:
+        """Inputs must be multiples of 2^5 in both dimensions (five pooling levels, noise_network.py:228-238)."""
+        return 32
+
+    def init_weights(self):
+        """He-normal for LeakyReLU(0.1) on every conv, zero biases; last layer 'linear' gain or zeros
+        (noise_network.py:165-184).  Draws from the global CPU generator in the reference's module order, with the
+        reference's shapes, so the same torch seed gives the same network."""
+        order = [l for l in self.layers if not l.name.startswith("output_block")]
+        ob = {l.name: l for l in self.layers if l.name.startswith("output_block")}
+        order += [ob["output_block.4"], ob["output_block.0"], ob["output_block.2"]]   # output_conv is visited first
+        with torch.no_grad():
+            new = torch.zeros(self.nparams)
+            for l in order:
+                fan_in = l.cin * l.k * l.k
+                std = math.sqrt(2.0 / (1 + 0.1 ** 2)) / math.sqrt(fan_in)
+                new[l.w_off:l.w_off + l.M * fan_in] = torch.empty(l.M, l.cin, l.k, l.k).normal_(0, std).reshape(-1)
+            last = ob["output_block.4"]
+            n_last = last.M * last.cin
+            if self._zero_output_weights:
+                new[last.w_off:last.w_off + n_last] = 0
+            else:
+                new[last.w_off:last.w_off + n_last] = torch.empty(last.M, last.cin, 1, 1).normal_(0, 1.0 / math.sqrt(last.cin)).reshape(-1)
+            self._flat.copy_(new)
+        self.mark_dirty()
+
+    def mark_dirty(self):
+        """Parameters changed outside the fused optimiser: the fp16 MFMA shadows must be re-packed before the next run."""
+        self._version += 1
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        super()._load_from_state_dict(*args, **kwargs)
+        self.mark_dirty()
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        r = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.mark_dirty()
+        return r
+
+    # ---- execution --------------------------------------------------------------------------------------------
+    def _engine(self, B: int, H: int, W: int):
+        from ssdn.hip import lib as L
+        from ssdn.hip.engine import DeviceNet
+        from ssdn.hip.graph import NetPlan
+        if self._flat.device.type != "cuda":
+            raise L.SsdnHipError("NoiseNetwork.forward needs an MI355X: parameters live on %s and the ssdn hot path has no CPU "
+                                 "fallback" % self._flat.device)
+        key = (B, H, W)
+        if key not in self._engines:
+            cus = L.load().ssdn_device_cus()
+            plan = NetPlan("n/", self.in_channels, self.out_channels, self._blindspot, B, H, W, cus=cus, train=False)
+            self._engines[key] = [DeviceNet(plan, self._flat.device, self._flat, None), -1]
+        return self._engines[key]
+
+    def forward(self, x: Tensor) -> Tensor:
+        """x: float32 [B,C,H,W] (H, W multiples of 32; square when blindspot) -> float32 [B,out_channels,H,W] on the GPU."""
+        from ssdn.hip.engine import current_stream
+        if x.dim() != 4 or x.shape[1] != self.in_channels:
+            raise ValueError("expected input [B,%d,H,W], got %s" % (self.in_channels, tuple(x.shape)))
+        B, _, H, W = x.shape
+        slot = self._engine(B, H, W)
+        eng = slot[0]
+        s = current_stream()
+        if slot[1] != self._version:
+            eng.pack.run(s)
+            slot[1] = self._version
+        eng.tensor("in32").copy_(x.to(dtype=torch.float32), non_blocking=True)
+        eng.fwd.run(s)
+        return eng.tensor("out32").clone()

