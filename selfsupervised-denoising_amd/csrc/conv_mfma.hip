@@ -10,7 +10,9 @@
 // B = the input halo tile staged ONCE in LDS as NHWC fp16 (every tap is a different LDS offset of the same tile).
 //   workgroup = 256 threads = 4 waves; tile = up to 256 output pixels (2^ltn images x 2^lth rows x 2^ltw cols)
 //   wave w owns pixels [64w, 64w+64) = two 32-wide MFMA column tiles, and all MT (<=3) 32-row output-channel tiles
-//   LDS: halo tile [TN][TH+padT+padB][TW+padL+padR] pixels x (kc fp16 + 16 B pad)  +  one weight slice [32*MT][kc] (+pad)
+//   LDS: halo tile [TN][TH+padT+padB][TW+padL+padR] pixels x (kc fp16 + 16 B pad)  +  TWO weight slices [32*MT][kc] (+pad):
+//   the slice of step s+1 (next tap / channel chunk) is prefetched global->registers while step s runs on the MFMA pipe
+//   and committed to the idle buffer afterwards -- one barrier per step, L2 latency of the weight stream hidden.
 //   pixel / weight row stride = 16 B x odd  =>  ds_read_b128 of 16 different pixels hits 16 different 16-B bank slots.
 #include "common.h"
 
@@ -48,17 +50,21 @@ static inline unsigned magic_of(unsigned d) { return (unsigned)((0x100000000ull 
 
 struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
-    int lg;                 // log2(threads cooperating on one pixel / weight row when staging)
+    unsigned mg_cc8;        // magic reciprocal of cc8
+    int lg;                 // log2(threads cooperating on one pixel when staging the tile)
     int cc8;                // 16-B chunks per pixel per channel chunk (= kc/8)
     int m_base;             // first output channel of this launch (multiple of 32)
 };
+
+#define CONV_NW 9  // weight-slice prefetch registers per thread (16 B each): covers MT*32 rows x kc<=192 channels
 
 template <int MT>
 __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, a.kc);
     char* tile = smem;
-    char* wl = smem + (size_t)g.NP * g.PSTR;
+    char* wl0 = smem + (size_t)g.NP * g.PSTR;           // two weight-slice buffers (double buffering)
+    const int wbuf_bytes = MT * 32 * g.WSTR;
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
     // tile origin
@@ -97,38 +103,75 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux
     const h16* s1 = (const h16*)a.src1.p;
     const h16* wp = (const h16*)a.w;
 
-    for (int ch = 0; ch < nchunks; ++ch) {
-        __syncthreads();  // everyone is done reading the previous channel chunk
-        // ---- stage the input halo tile (channels [ch*kc, ch*kc+kc)) ------------------------------------------
+    // weight-slice prefetch: element e = tid + 256*i  ->  row e / cc8, 16-B chunk e % cc8
+    const int wtotal = MT * 32 * x.cc8;
+    int w_goff[CONV_NW], w_loff[CONV_NW];
+#pragma unroll
+    for (int i = 0; i < CONV_NW; ++i) {
+        int e = tid + i * CONV_THREADS;
+        int m = fdiv(e, x.mg_cc8);
+        int cc = e - m * x.cc8;
+        w_goff[i] = e < wtotal ? ((x.m_base + m) * a.Ktot + cc * 8) : -1;
+        w_loff[i] = m * g.WSTR + cc * 16;
+    }
+    half8 wreg[CONV_NW];
+    auto w_issue = [&](int ch, int t) {
+        const h16* base = wp + (long long)t * a.Mpad * a.Ktot + ch * a.kc;
+#pragma unroll
+        for (int i = 0; i < CONV_NW; ++i)
+            if (w_goff[i] >= 0) wreg[i] = ld_h8(base + w_goff[i]);
+    };
+    auto w_commit = [&](char* buf) {
+#pragma unroll
+        for (int i = 0; i < CONV_NW; ++i)
+            if (w_goff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wreg[i];
+    };
+    auto stage_tile = [&](int ch) {
         if (sub < x.cc8) {
             const int k = ch * a.kc + sub * 8;
-            for (int hp = grp; hp < g.NP; hp += ngrp) {
-                unsigned r1 = fdiv(hp, x.mg_hw);
-                int hx = hp - r1 * g.HW;
-                unsigned tn = fdiv(r1, x.mg_hh);
-                int hy = r1 - tn * g.HH;
-                int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
-                half8 v = zero_h8();
-                if (n < a.N && y >= 0 && y < a.H && xx >= 0 && xx < a.W) {
-                    if (k < a.c0) {
-                        int ys = a.up0 ? (y >> 1) : y, xs = a.up0 ? (xx >> 1) : xx;
-                        v = ld_h8(s0 + (((long long)n * H0 + ys) * W0 + xs) * a.src0.cs + a.src0.co + k);
-                    } else {
-                        v = ld_h8(s1 + (((long long)n * a.H + y) * a.W + xx) * a.src1.cs + a.src1.co + (k - a.c0));
-                    }
+            const bool from0 = k < a.c0;
+            const h16* sp = from0 ? s0 + a.src0.co + k : s1 + a.src1.co + (k - a.c0);
+            const int scs = from0 ? a.src0.cs : a.src1.cs;
+            const int sh = from0 && a.up0 ? 1 : 0;
+            const int Hs = from0 ? H0 : a.H, Ws = from0 ? W0 : a.W;
+            for (int hp0 = grp; hp0 < g.NP; hp0 += 4 * ngrp) {
+                half8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int hp = hp0 + u * ngrp;
+                    unsigned r1 = fdiv(hp, x.mg_hw);
+                    int hx = hp - r1 * g.HW;
+                    unsigned tn = fdiv(r1, x.mg_hh);
+                    int hy = r1 - tn * g.HH;
+                    int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
+                    v[u] = zero_h8();
+                    if (hp < g.NP && n < a.N && y >= 0 && y < a.H && xx >= 0 && xx < a.W)
+                        v[u] = ld_h8(sp + (((long long)n * Hs + (y >> sh)) * Ws + (xx >> sh)) * scs);
                 }
-                *reinterpret_cast<half8*>(tile + (size_t)hp * g.PSTR + sub * 16) = v;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    int hp = hp0 + u * ngrp;
+                    if (hp < g.NP) *reinterpret_cast<half8*>(tile + (size_t)hp * g.PSTR + sub * 16) = v[u];
+                }
             }
         }
-        for (int t = 0; t < a.ntaps; ++t) {
-            __syncthreads();  // tile visible (t == 0) / previous tap's weight slice no longer read
-            if (sub < x.cc8) {
-                for (int m = grp; m < MT * 32; m += ngrp) {
-                    half8 v = ld_h8(wp + ((long long)t * a.Mpad + x.m_base + m) * a.Ktot + ch * a.kc + sub * 8);
-                    *reinterpret_cast<half8*>(wl + (size_t)m * g.WSTR + sub * 16) = v;
-                }
-            }
-            __syncthreads();
+    };
+
+    // ---- software pipeline over (channel chunk, tap) steps: weights of step s+1 are fetched into registers while
+    //      step s runs on the matrix cores, committed to the other LDS buffer afterwards; one barrier per step ----
+    const int nsteps = nchunks * a.ntaps;
+    w_issue(0, 0);
+    stage_tile(0);
+    w_commit(wl0);
+    __syncthreads();
+    int ch = 0, t = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        int nch = ch, nt_ = t + 1;
+        if (nt_ == a.ntaps) { nt_ = 0; ++nch; }
+        const bool more = step + 1 < nsteps;
+        if (more) w_issue(nch, nt_);
+        {
+            const char* wl = wl0 + (step & 1) * wbuf_bytes;
             const int toff = (a.dy[t] * g.HW + a.dx[t]) * g.PSTR;
             const char* b0p = tile + bbase[0] + toff;
             const char* b1p = tile + bbase[1] + toff;
@@ -144,6 +187,15 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux
                 }
             }
         }
+        if (more) {
+            if (nch != ch) {           // next step starts a new channel chunk: the tile is re-staged once everyone is done
+                __syncthreads();
+                stage_tile(nch);
+            }
+            w_commit(wl0 + ((step + 1) & 1) * wbuf_bytes);
+        }
+        __syncthreads();
+        ch = nch; t = nt_;
     }
 
     // ---- epilogue: D row = 8*(r>>2) + 4*(lane>>5) + (r&3)  (output channel), D col = lane&31 (pixel) -------------
@@ -195,7 +247,7 @@ static int conv_validate(const ssdn_conv_args* a) {
     if (a->ltw + a->lth + a->ltn > 8 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 256 pixels");
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 15)) return ssdn_set_error("conv: Ktot must equal c0+c1 and be a multiple of 16");
     if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("conv: source channel counts must be multiples of 8");
-    if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc) return ssdn_set_error("conv: kc must be a multiple of 16 dividing Ktot");
+    if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc || a->kc > 192) return ssdn_set_error("conv: kc must be a multiple of 16 (<= 192) dividing Ktot");
     if ((a->Mpad & 31) || a->M > a->Mpad) return ssdn_set_error("conv: Mpad must be a multiple of 32 and >= M");
     if (!a->dst32 && (a->M & 3)) return ssdn_set_error("conv: fp16 output needs M %% 4 == 0");
     if (a->up0 && ((a->H | a->W) & 1)) return ssdn_set_error("conv: upsampled source needs even H, W");
@@ -208,12 +260,12 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     int mt = a->Mpad / 32;
     if (mt > 3) mt = 3;
-    return g.NP * g.PSTR + mt * 32 * g.WSTR;
+    return g.NP * g.PSTR + 2 * mt * 32 * g.WSTR;
 }
 
 template <int MT>
 static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
-    size_t lds = (size_t)g.NP * g.PSTR + (size_t)MT * 32 * g.WSTR;
+    size_t lds = (size_t)g.NP * g.PSTR + 2 * (size_t)MT * 32 * g.WSTR;
     if (lds > 160 * 1024) return ssdn_set_error("conv: tiling needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
@@ -245,6 +297,7 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     x.mg_hw = magic_of(g.HW);
     x.mg_hh = magic_of(g.HH);
     x.cc8 = a->kc / 8;
+    x.mg_cc8 = magic_of(x.cc8);
     x.lg = 0;
     while ((1 << x.lg) < x.cc8) ++x.lg;
     if (x.lg > 8) return ssdn_set_error("conv: kc too large");

@@ -330,28 +330,38 @@ int launch_wpack(const ssdn_wpack_args* a, hipStream_t s) {
 // WREDUCE: ordered sum of the per-workgroup weight-gradient slabs -> fp32 OIHW gradient
 // ------------------------------------------------------------------------------------------------
 __global__ void k_wreduce(ssdn_wreduce_args a) {
+    // one thread per slab element in SLAB order (k fastest): every slab is read with fully coalesced 4-byte loads,
+    // slabs are summed in index order (deterministic), 8 independent loads in flight per thread.
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long nw = (long long)a.M * a.cin * a.ntaps;
+    long long stride = (long long)a.ntaps * a.Mpad * a.Kpad;
     float inv = a.inv_scale ? *a.inv_scale : 1.f;
-    if (idx < nw) {
-        int t = idx % a.ntaps;
-        int ci = (idx / a.ntaps) % a.cin;
-        int m = idx / ((long long)a.ntaps * a.cin);
-        int k = ci;  // real channels are contiguous in k (padding sits at the tail of the 2nd source only)
-        long long off = ((long long)t * a.Mpad + m) * a.Kpad + k;
-        long long stride = (long long)a.ntaps * a.Mpad * a.Kpad;
-        float acc = 0.f;
-        for (int s = 0; s < a.nslabs; ++s) acc += a.slab[s * stride + off];
-        a.gw[((long long)(a.m_off + m) * a.cin_full + a.c_off + ci) * a.ntaps + t] = acc * inv;
-    } else if (idx < nw + a.M && a.gb) {
-        int m = idx - nw;
+    if (idx < stride) {
+        int k = idx % a.Kpad;
+        int m = (idx / a.Kpad) % a.Mpad;
+        int t = idx / ((long long)a.Kpad * a.Mpad);
+        if (k < a.cin && m < a.M) {
+            const float* p = a.slab + idx;
+            float acc = 0.f;
+            int s = 0;
+            for (; s + 8 <= a.nslabs; s += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * stride];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) acc += v[u];
+            }
+            for (; s < a.nslabs; ++s) acc += p[(long long)s * stride];
+            a.gw[((long long)(a.m_off + m) * a.cin_full + a.c_off + k) * a.ntaps + t] = acc * inv;
+        }
+    } else if (idx < stride + a.M && a.gb) {
+        int m = idx - stride;
         float acc = 0.f;
         for (int s = 0; s < a.nslabs; ++s) acc += a.bslab[(long long)s * a.Mpad + m];
         a.gb[a.m_off + m] = acc * inv;
     }
 }
 int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s) {
-    long long n = (long long)a->M * a->cin * a->ntaps + a->M;
+    long long n = (long long)a->ntaps * a->Mpad * a->Kpad + a->M;
     hipLaunchKernelGGL(k_wreduce, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }

@@ -10,10 +10,14 @@ Nothing here touches a device; this module is pure Python.
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Tuple
 
 LDS_LIMIT = 160 * 1024
+# conv tilings at or below this many bytes of LDS are preferred: two workgroups then share a CU, so one workgroup's
+# tile staging / barriers overlap the other's MFMA work (tunable for experiments)
+CONV_LDS_PREFERRED = int(os.environ.get("SSDN_CONV_LDS_PREFERRED", 80 * 1024))
 TAPS_BLIND = [(ky - 2, kx - 1) for ky in range(3) for kx in range(3)]   # ShiftConv2d: in[y+ky-2, x+kx-1]
 TAPS_PLAIN = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 TAPS_1x1 = [(0, 0)]
@@ -133,11 +137,11 @@ def _pow2ceil_log(v: int) -> int:
 
 
 def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT):
-    """Pick (ltw, lth, ltn, kc) for SSDN_OP_CONV: <= 256 pixels per workgroup, LDS = halo tile + one weight slice."""
+    """Pick (ltw, lth, ltn, kc) for SSDN_OP_CONV: <= 256 pixels per workgroup, LDS = halo tile + two weight slices."""
     padT, padB, padL, padR = _pads(taps)
     mt = min(3, Mpad // 32)
     best = None
-    kcs = [kc for kc in range(16, Ktot + 1, 16) if Ktot % kc == 0]
+    kcs = [kc for kc in range(16, min(Ktot, 192) + 1, 16) if Ktot % kc == 0]
     for ltw in range(0, min(5, _pow2ceil_log(W)) + 1):
         for lth in range(0, min(8 - ltw, _pow2ceil_log(H)) + 1):
             for ltn in range(0, min(8 - ltw - lth, _pow2ceil_log(N)) + 1):
@@ -146,12 +150,13 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT):
                 util = (N * H * W) / (tiles * 256.0)       # MFMA lanes doing useful work
                 NP = TN * (TH + padT + padB) * (TW + padL + padR)
                 for kc in kcs:
-                    lds = NP * (kc * 2 + 16) + mt * 32 * (kc * 2 + 16)
+                    lds = NP * (kc * 2 + 16) + 2 * mt * 32 * (kc * 2 + 16)
                     if lds > budget:
                         continue
                     halo = NP / float(TN * TH * TW)
-                    # prefer: high utilisation, then whole-K residency (fewer barriers), then small halo, then wide tiles
-                    key = (round(util, 3), kc, -round(halo, 3), ltw)
+                    # prefer: high utilisation, then 2 workgroups per CU, then large channel chunks (fewer barriers),
+                    # then small halo, then wide tiles
+                    key = (round(util, 3), lds <= CONV_LDS_PREFERRED and kc >= min(48, Ktot), kc, -round(halo, 3), ltw)
                     if best is None or key > best[0]:
                         best = (key, (ltw, lth, ltn, kc))
     if best is None:

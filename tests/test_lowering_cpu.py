@@ -65,6 +65,6 @@ def test_plan_tilings_fit_lds():
                 padT = max(0, -min(t[0] for t in a["taps"])); padB = max(0, max(t[0] for t in a["taps"]))
                 padL = max(0, -min(t[1] for t in a["taps"])); padR = max(0, max(t[1] for t in a["taps"]))
                 NP = (1 << a["ltn"]) * ((1 << a["lth"]) + padT + padB) * ((1 << a["ltw"]) + padL + padR)
-                lds = NP * (a["kc"] * 2 + 16) + min(3, a["Mpad"] // 32) * 32 * (a["kc"] * 2 + 16)
+                lds = NP * (a["kc"] * 2 + 16) + 2 * min(3, a["Mpad"] // 32) * 32 * (a["kc"] * 2 + 16)
                 assert lds <= LDS_LIMIT
                 assert a["ltw"] + a["lth"] + a["ltn"] <= 8
