@@ -12,8 +12,11 @@
  * Conventions
  *   - all device pointers are caller-owned (the Python host allocates them with torch on the
  *     current device); the library allocates nothing and keeps no state besides the last error.
- *   - activation tensors: NHWC, fp16, `cs` = elements per pixel (channel stride), `co` = channel offset
+ *   - activation tensors: NHWC, 16-bit, `cs` = elements per pixel (channel stride), `co` = channel offset
  *     of this view inside the pixel, so concatenations / channel slices are views, never copies.
+ *     FORWARD activations are fp16 (11-bit significand: the eval PSNR budget of +-0.05 dB needs it);
+ *     every GRADIENT tensor of the backward pass is bf16 (fp32 exponent range: the SSDN loss gradient spans > 7 decades
+ *     between pixels when sigma is estimated / Poisson, which no fp16 loss scale can hold) -- accumulation is fp32 always.
  *   - every function returns 0 on success; on failure a negative code and ssdn_last_error() gives text.
  *     No C++ exception crosses the boundary.
  *   - `stream` is a hipStream_t (NULL = the default stream); all work is enqueued asynchronously.
@@ -90,7 +93,9 @@ typedef struct ssdn_pack_input_args {
  * IN is the virtual channel-concatenation [src0 (c0 ch), src1 (c1 ch)], zero outside [0,H)x[0,W);
  * src0 is read at (y>>1, x>>1) when up0 (nearest 2x upsample folded into the load).
  * Wp is fp16 [ntaps][Mpad][Ktot] (packed by SSDN_OP_WPACK), Ktot = c0+c1 (multiple of 16), Mpad multiple of 32.
- * Output: dst (fp16 NHWC view) or, when dst32 != NULL, fp32 NCHW planar [N][M][H][W] (net_out). */
+ * Output: dst (16-bit NHWC view) or, when dst32 != NULL, fp32 NCHW planar [N][M][H][W] (net_out).
+ * bf16 = 0: src0/src1/w/dst/add are fp16 (forward role).  bf16 = 1: they are bf16 (data-gradient role); `mask` is
+ * always an fp16 saved activation. */
 typedef struct ssdn_conv_args {
     ssdn_view src0;
     ssdn_view src1;
@@ -110,6 +115,7 @@ typedef struct ssdn_conv_args {
     /* tiling chosen by the host (see ssdn/hip/graph.py): tile = 2^ltn images x 2^lth rows x 2^ltw cols = 256 px */
     int32_t ltw, lth, ltn;
     int32_t kc; /* channel chunk staged in LDS at a time (multiple of 16, divides Ktot) */
+    int32_t bf16;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -149,7 +155,8 @@ typedef struct ssdn_unrot_args {
 } ssdn_unrot_args;
 
 /* ---- SSDN_OP_WGRAD --------------------------------------------------------------------------
- * replaces: autograd's conv weight/bias gradient.  Every workgroup s < nslabs reduces its share of pixels into
+ * replaces: autograd's conv weight/bias gradient.  dz is bf16, IN is fp16 (converted to bf16 while it is staged in
+ * LDS; products are exact in the fp32 accumulator).  Every workgroup s < nslabs reduces its share of pixels into
  *   slab[s][t][m][k] = sum_pixels dz(n,y,x,m) * IN(n, y+dy[t], x+dx[t], k)      (fp32, [nslabs][ntaps][Mpad][Kpad])
  *   bslab[s][m]      = sum_pixels dz(n,y,x,m)
  * IN as in SSDN_OP_CONV.  Deterministic: fixed pixel->workgroup assignment, SSDN_OP_WREDUCE sums slabs in order. */
@@ -188,7 +195,7 @@ typedef struct ssdn_wreduce_args {
 /* ---- SSDN_OP_WPACK --------------------------------------------------------------------------
  * fp32 OIHW master weights -> the two fp16 shadows the MFMA kernels read:
  *   wf[t][m][k]  (forward role)  = W[m][cin(k)][t]  for m < M, k real; 0 in the padding   [ntaps][Mpad_f][Ktot]
- *   wd[t][c][m]  (dgrad role)    = W[m][cin(c)][t]                                        [ntaps][Mpad_d][Kd]
+ *   wd[t][c][m]  (dgrad role)    = W[m][cin(c)][t]   stored as bf16                       [ntaps][Mpad_d][Kd]
  * k -> cin: k < c0 ? k : (k - c0 < c1_real ? c0 + k - c0 : padding). */
 typedef struct ssdn_wpack_args {
     const float* w; /* [M][cin][ntaps] */
@@ -201,9 +208,9 @@ typedef struct ssdn_wpack_args {
 } ssdn_wpack_args;
 
 /* ---- SSDN_OP_GRAD_PACK ----------------------------------------------------------------------
- * fp32 NCHW gradient w.r.t. net_out -> fp16 NHWC [N,H,W,cpad] times a power-of-two loss scale chosen from the
- * running max |g| (gmax, written by the loss kernels with atomicMax on the float bits) so that fp16 neither
- * overflows nor underflows further down the backward pass; writes scale_out[0] = scale, scale_out[1] = 1/scale. */
+ * fp32 NCHW gradient w.r.t. net_out -> bf16 NHWC [N,H,W,cpad] (zero padded channels).  bf16 keeps the fp32 exponent
+ * range, so there is NO loss scaling; scale_out[0] = scale_out[1] = 1 is written for SSDN_OP_WREDUCE's inv_scale input.
+ * gmax (float bits of max |g|, written by the loss kernels with atomicMax) is kept as an overflow / NaN sentinel. */
 typedef struct ssdn_grad_pack_args {
     const float* g; /* [N,C,H,W] */
     ssdn_view dst;

@@ -19,8 +19,11 @@ import torch
 LRELU = 0.1
 
 
-def _r16(t, on):
-    return t.half().float() if on else t
+def _r16(t, on, kind="act"):
+    """storage rounding of the device: fp16 for forward activations / forward weights, bf16 for gradients / dgrad weights"""
+    if not on:
+        return t
+    return t.bfloat16().to(t.dtype) if kind in ("actb", "bf16") else t.half().to(t.dtype)
 
 
 def _lgrad(act):
@@ -49,7 +52,7 @@ class Interp:
         return self.t[name]
 
     def store(self, v, c, val):
-        self.alloc(v.t)[..., v.co:v.co + c] = _r16(val, self.fp16)
+        self.alloc(v.t)[..., v.co:v.co + c] = _r16(val, self.fp16, self.plan.tensors[v.t].kind)
 
     def weight(self, lname):
         l = self.L[lname]
@@ -86,7 +89,7 @@ class Interp:
                 ci = kmap[c]
                 if ci >= 0:
                     wd[:, c, :M] = w[:, ci, :].t()
-            self.t[self.plan.prefix + "wd/" + layer] = _r16(wd, self.fp16)
+            self.t[self.plan.prefix + "wd/" + layer] = _r16(wd, self.fp16, "bf16")
 
     def _gather(self, src0, src1, c0, c1, up0, N, H, W):
         parts = []
@@ -113,7 +116,7 @@ class Interp:
         return out
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
-                ltw, lth, ltn, kc):
+                ltw, lth, ltn, kc, bf16=0):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -186,17 +189,13 @@ class Interp:
 
     def op_grad_pack(self, g, dst, N, C, H, W, cpad):
         gg = self.t[g].reshape(N, C, H, W)
-        mx = float(gg.abs().max())
-        self.scale = 1.0
-        if mx > 0 and math.isfinite(mx):
-            _, e = math.frexp(np.float32(mx))
-            self.scale = math.ldexp(1.0, 4 - e)
+        self.scale = 1.0                       # bf16 gradients: no loss scaling
         out = torch.zeros(N, H, W, cpad)
-        out[..., :C] = gg.permute(0, 2, 3, 1) * self.scale
+        out[..., :C] = gg.permute(0, 2, 3, 1)
         self.store(dst, cpad, out)
 
     def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn):
-        x = self._gather(src0, src1, c0, c1, up0, N, H, W)
+        x = _r16(self._gather(src0, src1, c0, c1, up0, N, H, W), self.fp16, "bf16")   # staged as bf16 on the device
         g = self.view(dz, M)
         self.slab = torch.zeros(len(taps), Mpad, Kpad)
         for t, (dy, dx) in enumerate(taps):

@@ -8,6 +8,9 @@ typedef _Float16 h16;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -28,6 +31,24 @@ static __device__ __forceinline__ half8 ld_h8(const h16* p) { return *reinterpre
 static __device__ __forceinline__ void st_h8(h16* p, half8 v) { *reinterpret_cast<half8*>(p) = v; }
 static __device__ __forceinline__ half4 ld_h4(const h16* p) { return *reinterpret_cast<const half4*>(p); }
 static __device__ __forceinline__ void st_h4(h16* p, half4 v) { *reinterpret_cast<half4*>(p) = v; }
+
+// ---- bf16 (gradient tensors): stored as raw 16-bit words; round-to-nearest-even from fp32, NaN kept quiet ----
+static __device__ __forceinline__ unsigned short f2bf(float f) {
+    unsigned u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+}
+static __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+static __device__ __forceinline__ u16x8 ld_b8(const unsigned short* p) { return *reinterpret_cast<const u16x8*>(p); }
+static __device__ __forceinline__ void st_b8(unsigned short* p, u16x8 v) { *reinterpret_cast<u16x8*>(p) = v; }
+static __device__ __forceinline__ u16x4 ld_b4(const unsigned short* p) { return *reinterpret_cast<const u16x4*>(p); }
+static __device__ __forceinline__ void st_b4(unsigned short* p, u16x4 v) { *reinterpret_cast<u16x4*>(p) = v; }
+static __device__ __forceinline__ u16x8 zero_b8() {
+    u16x8 z;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) z[i] = 0;
+    return z;
+}
 
 static __device__ __forceinline__ half8 zero_h8() {
     half8 z;

@@ -58,7 +58,17 @@ struct ConvAux {  // host-computed helpers passed by value
 
 #define CONV_NW 9  // weight-slice prefetch registers per thread (16 B each): covers MT*32 rows x kc<=192 channels
 
-template <int MT>
+template <bool BF>
+static __device__ __forceinline__ f32x16 mma(half8 av, half8 bv, f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+}
+
+// BF = false: fp16 operands / fp16 output (forward);  BF = true: bf16 operands / bf16 output (data gradient).
+// Tiles are moved through LDS as raw 16-bit words, so only the MFMA opcode and the epilogue conversions differ.
+template <int MT, bool BF>
 __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, a.kc);
@@ -182,8 +192,8 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     half8 av = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR + s * 2);
-                    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b0, acc[mt][0], 0, 0, 0);
-                    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, b1, acc[mt][1], 0, 0, 0);
+                    acc[mt][0] = mma<BF>(av, b0, acc[mt][0]);
+                    acc[mt][1] = mma<BF>(av, b1, acc[mt][1]);
                 }
             }
         }
@@ -224,19 +234,32 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux
                     continue;
                 }
                 if (a.add.p) {
-                    half4 ad = ld_h4((const h16*)a.add.p + pix * a.add.cs + a.add.co + m);
+                    if constexpr (BF) {
+                        u16x4 ad = ld_b4((const unsigned short*)a.add.p + pix * a.add.cs + a.add.co + m);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] += (float)ad[j];
+                        for (int j = 0; j < 4; ++j) v[j] += bf2f(ad[j]);
+                    } else {
+                        half4 ad = ld_h4((const h16*)a.add.p + pix * a.add.cs + a.add.co + m);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] += (float)ad[j];
+                    }
                 }
                 if (a.mask.p) {
                     half4 mk = ld_h4((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) v[j] *= lrelu_grad((float)mk[j]);
                 }
-                half4 o;
+                if constexpr (BF) {
+                    u16x4 o;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) o[j] = (h16)v[j];
-                st_h4((h16*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+                    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
+                    st_b4((unsigned short*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+                } else {
+                    half4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) o[j] = (h16)v[j];
+                    st_h4((h16*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+                }
             }
         }
     }
@@ -252,6 +275,7 @@ static int conv_validate(const ssdn_conv_args* a) {
     if (!a->dst32 && (a->M & 3)) return ssdn_set_error("conv: fp16 output needs M %% 4 == 0");
     if (a->up0 && ((a->H | a->W) & 1)) return ssdn_set_error("conv: upsampled source needs even H, W");
     if (a->c1 > 0 && !a->src1.p) return ssdn_set_error("conv: src1 missing");
+    if (a->bf16 && a->dst32) return ssdn_set_error("conv: fp32 output is only implemented for the fp16 (forward) role");
     return 0;
 }
 
@@ -263,13 +287,13 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
     return g.NP * g.PSTR + 2 * mt * 32 * g.WSTR;
 }
 
-template <int MT>
+template <int MT, bool BF>
 static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
     size_t lds = (size_t)g.NP * g.PSTR + 2 * (size_t)MT * 32 * g.WSTR;
     if (lds > 160 * 1024) return ssdn_set_error("conv: tiling needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     int grid = g.tiles_x * g.tiles_y * g.groups_n;
@@ -283,7 +307,7 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
         double flops = 2.0 * px * m_real * a->Ktot * a->ntaps;
         double bytes = px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
         prof_begin(3 - MT, s);
-        hipLaunchKernelGGL(k_conv<MT>, dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
+        hipLaunchKernelGGL((k_conv<MT, BF>), dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
         prof_end(3 - MT, s, flops, bytes);
     }
     return 0;
@@ -304,13 +328,14 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     x.m_base = 0;
     // output channels in launches of 96 (MT=3); the tail uses MT = 1 or 2
     int full = a->Mpad / 96, rem = (a->Mpad % 96) / 32;
+    const bool bf = a->bf16 != 0;
     if (full) {
-        rc = conv_launch_mt<3>(a, g, x, full, s);
+        rc = bf ? conv_launch_mt<3, true>(a, g, x, full, s) : conv_launch_mt<3, false>(a, g, x, full, s);
         if (rc) return rc;
     }
     x.m_base = full * 96;
-    if (rem == 2) rc = conv_launch_mt<2>(a, g, x, 1, s);
-    else if (rem == 1) rc = conv_launch_mt<1>(a, g, x, 1, s);
+    if (rem == 2) rc = bf ? conv_launch_mt<2, true>(a, g, x, 1, s) : conv_launch_mt<2, false>(a, g, x, 1, s);
+    else if (rem == 1) rc = bf ? conv_launch_mt<1, true>(a, g, x, 1, s) : conv_launch_mt<1, false>(a, g, x, 1, s);
     if (rc) return rc;
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;

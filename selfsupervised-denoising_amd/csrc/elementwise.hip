@@ -95,8 +95,8 @@ __global__ void k_pool_bwd(ssdn_pool_args a) {
     int i = (p / Wo) % Ho;
     int n = p / ((long long)Wo * Ho);
     const h16* act = (const h16*)a.act.p + a.act.co + c;
-    h16* dz = (h16*)a.dz.p + a.dz.co + c;
-    half8 g = ld_h8((const h16*)a.dpool.p + a.dpool.co + c + (((long long)n * Ho + i) * Wo + j) * a.dpool.cs);
+    unsigned short* dz = (unsigned short*)a.dz.p + a.dz.co + c;                     // gradients are bf16
+    u16x8 g = ld_b8((const unsigned short*)a.dpool.p + a.dpool.co + c + (((long long)n * Ho + i) * Wo + j) * a.dpool.cs);
     int r0 = a.shifted ? 2 * i - 1 : 2 * i;
     half8 v[4];
     float m[8];
@@ -123,21 +123,21 @@ __global__ void k_pool_bwd(ssdn_pool_args a) {
     for (int k = 0; k < 4; ++k) {
         int y = r0 + (k >> 1);
         if (y < 0) continue;
-        half8 o;
+        u16x8 o;
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
             float av = (float)v[k][q];
             bool hit = !taken[q] && av == m[q];
             if (hit) taken[q] = true;
-            o[q] = hit ? (h16)((float)g[q] * lrelu_grad(av)) : (h16)0.f;
+            o[q] = hit ? f2bf(bf2f(g[q]) * lrelu_grad(av)) : (unsigned short)0;
         }
-        st_h8(dz + (((long long)n * a.H + y) * a.W + 2 * j + (k & 1)) * a.dz.cs, o);
+        st_b8(dz + (((long long)n * a.H + y) * a.W + 2 * j + (k & 1)) * a.dz.cs, o);
     }
     // shifted pooling never looks at the last row: its gradient is zero
     if (a.shifted && i == Ho - 1) {
-        half8 z = zero_h8();
-        st_h8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j) * a.dz.cs, z);
-        st_h8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j + 1) * a.dz.cs, z);
+        u16x8 z = zero_b8();
+        st_b8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j) * a.dz.cs, z);
+        st_b8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j + 1) * a.dz.cs, z);
     }
 }
 int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s) {
@@ -160,19 +160,19 @@ __global__ void k_upsum_bwd(ssdn_upsum_args a) {
     int j = p % a.W;
     int i = (p / a.W) % a.H;
     int n = p / ((long long)a.W * a.H);
-    const h16* src = (const h16*)a.src.p + a.src.co + c;
+    const unsigned short* src = (const unsigned short*)a.src.p + a.src.co + c;   // bf16 gradient
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        half8 v = ld_h8(src + (((long long)n * 2 * a.H + 2 * i + (k >> 1)) * 2 * a.W + 2 * j + (k & 1)) * a.src.cs);
+        u16x8 v = ld_b8(src + (((long long)n * 2 * a.H + 2 * i + (k >> 1)) * 2 * a.W + 2 * j + (k & 1)) * a.src.cs);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) acc[q] += (float)v[q];
+        for (int q = 0; q < 8; ++q) acc[q] += bf2f(v[q]);
     }
     half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + p * a.mask.cs);
-    half8 o;
+    u16x8 o;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) o[q] = (h16)(acc[q] * lrelu_grad((float)mk[q]));
-    st_h8((h16*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
+    for (int q = 0; q < 8; ++q) o[q] = f2bf(acc[q] * lrelu_grad((float)mk[q]));
+    st_b8((unsigned short*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
 }
 int launch_upsum_bwd(const ssdn_upsum_args* a, hipStream_t s) {
     if (a->C & 7) return ssdn_set_error("upsum: C%%8 must be 0");
@@ -229,7 +229,7 @@ __global__ void k_unrot_bwd(ssdn_unrot_args a) {
     int y = (p / P) % P;
     int nb = p / ((long long)P * P);
     int r = nb / a.B, b = nb % a.B;
-    half8 o = zero_h8();
+    u16x8 o = zero_b8();
     int u = y + 1, v = x;
     if (u < P) {
         int i, j;
@@ -239,12 +239,12 @@ __global__ void k_unrot_bwd(ssdn_unrot_args a) {
             case 2: i = P - 1 - u; j = P - 1 - v; break;
             default: i = P - 1 - v; j = u; break;         // u = j, v = P-1-i
         }
-        half8 g = ld_h8((const h16*)a.src.p + a.src.co + r * a.C + c + (((long long)b * P + i) * P + j) * a.src.cs);
+        u16x8 g = ld_b8((const unsigned short*)a.src.p + a.src.co + r * a.C + c + (((long long)b * P + i) * P + j) * a.src.cs);
         half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + p * a.mask.cs);
 #pragma unroll
-        for (int q = 0; q < 8; ++q) o[q] = (h16)((float)g[q] * lrelu_grad((float)mk[q]));
+        for (int q = 0; q < 8; ++q) o[q] = f2bf(bf2f(g[q]) * lrelu_grad((float)mk[q]));
     }
-    st_h8((h16*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
+    st_b8((unsigned short*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
 }
 int launch_unrot_bwd(const ssdn_unrot_args* a, hipStream_t s) {
     if (a->C & 7) return ssdn_set_error("unrot: C%%8 must be 0");
@@ -256,33 +256,25 @@ int launch_unrot_bwd(const ssdn_unrot_args* a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // GRAD_PACK: fp32 NCHW loss gradient -> fp16 NHWC with a power-of-two loss scale
 // ------------------------------------------------------------------------------------------------
-static __device__ __forceinline__ float scale_from_gmax(uint32_t bits) {
-    float mx = __uint_as_float(bits);
-    if (!(mx > 0.f) || !isfinite(mx)) return 1.f;
-    // map max|g| to [8,16): 12 binades of head-room below the fp16 maximum for growth along the backward pass
-    int e;
-    frexpf(mx, &e);  // mx = f * 2^e, f in [0.5,1)
-    return ldexpf(1.f, 4 - e);
-}
 __global__ void k_grad_pack(ssdn_grad_pack_args a) {
+    // gradients travel as bf16 (fp32 exponent range): no loss scale is needed, scale_out is written as {1, 1}
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long HW = (long long)a.H * a.W;
     long long total = a.N * HW;
-    float scale = scale_from_gmax(*a.gmax);
-    if (idx == 0) {
-        a.scale_out[0] = scale;
-        a.scale_out[1] = 1.f / scale;
+    if (idx == 0 && a.scale_out) {
+        a.scale_out[0] = 1.f;
+        a.scale_out[1] = 1.f;
     }
     if (idx >= total) return;
     int n = idx / HW;
     long long pix = idx % HW;
-    h16* d = (h16*)a.dst.p + a.dst.co + idx * a.dst.cs;
+    unsigned short* d = (unsigned short*)a.dst.p + a.dst.co + idx * a.dst.cs;
     for (int c0 = 0; c0 < a.cpad; c0 += 8) {
-        half8 v = zero_h8();
+        u16x8 v = zero_b8();
 #pragma unroll
         for (int c = 0; c < 8; ++c)
-            if (c0 + c < a.C) v[c] = (h16)(a.g[((long long)n * a.C + c0 + c) * HW + pix] * scale);
-        st_h8(d + c0, v);
+            if (c0 + c < a.C) v[c] = f2bf(a.g[((long long)n * a.C + c0 + c) * HW + pix]);
+        st_b8(d + c0, v);
     }
 }
 int launch_grad_pack(const ssdn_grad_pack_args* a, hipStream_t s) {
@@ -317,7 +309,7 @@ __global__ void k_wpack(ssdn_wpack_args a) {
         int t = e / ((long long)a.Kd * a.Mpad_d);
         int ci = c < a.Ktot ? k_to_cin(c, a.c0, a.c1_real) : -1;
         float v = (m < a.M && ci >= 0) ? a.w[((long long)m * a.cin + ci) * a.ntaps + t] : 0.f;
-        ((h16*)a.wd)[e] = (h16)v;
+        ((unsigned short*)a.wd)[e] = f2bf(v);   // data-gradient shadow is bf16 (gradients are bf16)
     }
 }
 int launch_wpack(const ssdn_wpack_args* a, hipStream_t s) {

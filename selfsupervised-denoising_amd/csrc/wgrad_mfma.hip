@@ -102,9 +102,13 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
 
-    half8 ones;
+    half8 ones;   // bf16 1.0 = 0x3f80 in every 16-bit slot
+    {
+        u16x8 o;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) ones[i] = (h16)1.f;
+        for (int i = 0; i < 8; ++i) o[i] = 0x3f80;
+        ones = __builtin_bit_cast(half8, o);
+    }
 
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
     const h16* s0 = (const h16*)a.src0.p;
@@ -137,7 +141,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
                             v = ld_h8(s1 + (((long long)n * a.H + y) * a.W + xx) * a.src1.cs + a.src1.co + (k - a.c0));
                         }
                     }
-                    *reinterpret_cast<half8*>(xt + (size_t)hp * g.PSTR + sub * 16) = v;
+                    // fp16 activation -> bf16 once, while staging (the gradient operand is bf16; MFMA needs one type)
+                    u16x8 vb;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) vb[e] = f2bf((float)v[e]);
+                    *reinterpret_cast<u16x8*>(xt + (size_t)hp * g.PSTR + sub * 16) = vb;
                 }
             }
         }
@@ -185,7 +193,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
                 }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[mt], bf, acc[mt][j], 0, 0, 0);
+                    acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, bf),
+                                                                         acc[mt][j], 0, 0, 0);
             }
         }
     }

@@ -41,7 +41,8 @@ def current_stream() -> int:
 class DeviceNet:
     """One NoiseNetwork instance on the device for a fixed input shape: buffers + materialised fwd/bwd/pack op lists."""
 
-    DT = {"act": torch.float16, "f16": torch.float16, "f32": torch.float32, "u32": torch.int32, "i64": torch.int64}
+    DT = {"act": torch.float16, "actb": torch.bfloat16, "f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32,
+          "u32": torch.int32, "i64": torch.int64}
 
     def __init__(self, plan: NetPlan, device, params: torch.Tensor, grads: Optional[torch.Tensor],
                  shared: Optional[Dict[str, torch.Tensor]] = None):
@@ -97,6 +98,7 @@ class DeviceNet:
             s.mask, s.add, s.dst = self._view(a["mask"]), self._view(a["add"]), self._view(a["dst"])
             s.dst32 = _ptr(self.t[a["dst32"]]) if a["dst32"] is not None else None
             s.ltw, s.lth, s.ltn, s.kc = a["ltw"], a["lth"], a["ltn"], a["kc"]
+            s.bf16 = a["bf16"]
             if L.load().ssdn_conv_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("conv %s/%s: %s" % (a["layer"], a["role"], L.load().ssdn_last_error().decode()))
             return op.type, s

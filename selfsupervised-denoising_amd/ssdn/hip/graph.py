@@ -29,7 +29,8 @@ def ceil_to(v: int, m: int) -> int:
 
 @dataclass
 class TSpec:
-    """A tensor of the plan.  kind 'act': NHWC fp16 [N,H,W,C]; 'f32': flat fp32; 'f16': flat fp16; 'u32'; 'i64'."""
+    """A tensor of the plan.  kind 'act': NHWC fp16 [N,H,W,C] (forward activation); 'actb': NHWC bf16 (gradient);
+    'f32': flat fp32; 'f16' / 'bf16': flat 16-bit; 'u32'; 'i64'."""
     name: str
     kind: str
     shape: Tuple[int, ...]
@@ -230,6 +231,10 @@ class NetPlan:
     def act(self, name, N, H, W, C):
         return self.T(name, "act", (N, H, W, C))
 
+    def grad(self, name, N, H, W, C):
+        """gradient tensor: bf16 (include/ssdn_hip.h, conventions)"""
+        return self.T(name, "actb", (N, H, W, C))
+
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
               bias=True, act=True, mask=None, add=None):
         Ktot = c0 + c1
@@ -237,7 +242,7 @@ class NetPlan:
         ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad)
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                    taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
-                                   dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc)))
+                                   dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"))))
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
                m_off=0, c_off=0, with_bias=True):
@@ -331,7 +336,7 @@ class NetPlan:
             Mpad_d = ceil_to(rows, 32)
             self.T("wf/" + l.name, "f16", (l.ntaps * l.Mpad_f * l.Ktot,))
             if need_d:
-                self.T("wd/" + l.name, "f16", (l.ntaps * Mpad_d * l.Kd,))
+                self.T("wd/" + l.name, "bf16", (l.ntaps * Mpad_d * l.Kd,))
             self.pack.append(Op("wpack", dict(layer=l.name, M=l.M, cin=l.cin, ntaps=l.ntaps, c0=l.c0, c1_real=l.c1_real,
                                               Mpad_f=l.Mpad_f, Ktot=l.Ktot, Mpad_d=Mpad_d, Kd=l.Kd, need_d=need_d)))
         if not self.train:
@@ -343,7 +348,7 @@ class NetPlan:
         self.T("g32", "f32", (B, self.Cout, H, W))       # d mean(LOSS) / d net_out, written by the loss kernels
         self.T("gmax", "u32", (4,))
         self.T("scale", "f32", (4,))
-        gz = self.act("gz", B, H, W, 16)
+        gz = self.grad("gz", B, H, W, 16)
         b.append(Op("grad_pack", dict(g=self.prefix + "g32", dst=View(gz), N=B, C=self.Cout, H=H, W=W, cpad=16)))
 
         def dgrad(layer, src, csrc, n, h, w, taps, M, dst, mask=None, add=None):
@@ -353,13 +358,13 @@ class NetPlan:
         # output_block.4 : 96 -> Cout
         lo4 = L["output_block.4"]
         self._wgrad(lo4, View(gz), 16, View(nb), 96, 0, None, 0, 96, B, H, W, TAPS_1x1)
-        g_nb = self.act("g_nb", B, H, W, 96)
+        g_nb = self.grad("g_nb", B, H, W, 96)
         dgrad("output_block.4", gz, 16, B, H, W, TAPS_1x1, 96, View(g_nb), mask=View(nb))
         # output_block.2 : nin -> 96
         lo2 = L["output_block.2"]
         for ci in range(0, nin, 96):
             self._wgrad(lo2, View(g_nb), 96, View(na, ci), 96, 0, None, 0, 96, B, H, W, TAPS_1x1, c_off=ci, with_bias=(ci == 0))
-        g_na = self.act("g_na", B, H, W, nin)
+        g_na = self.grad("g_na", B, H, W, nin)
         dgrad("output_block.2", g_nb, 96, B, H, W, TAPS_1x1, nin, View(g_na), mask=View(na))
         # output_block.0 : nin -> nin
         lo0 = L["output_block.0"]
@@ -367,9 +372,9 @@ class NetPlan:
             for ci in range(0, nin, 96):
                 self._wgrad(lo0, View(g_na, mi), 96, View(head_in, ci), 96, 0, None, 0, 96, B, H, W, TAPS_1x1,
                             m_off=mi, c_off=ci, with_bias=(ci == 0))
-        g_d1b = self.act("g_d1b", N, H, W, 96)
+        g_d1b = self.grad("g_d1b", N, H, W, 96)
         if bs:
-            g_u = self.act("g_u", B, H, W, 384)
+            g_u = self.grad("g_u", B, H, W, 384)
             dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, View(g_u))
             b.append(Op("unrot_bwd", dict(src=View(g_u), dst=View(g_d1b), mask=View(d1b), B=B, P=H, C=96)))
         else:
@@ -378,7 +383,7 @@ class NetPlan:
         def dec_bwd(la, lb, ta, tb, g_tb, up_src, c_up, skip, c_skip, c_skip_real, h, w, tag, need_skip_grad=True):
             """backward of conv_b(conv_a(cat(up(up_src), skip))); returns (g_up_src, view of the skip gradient)."""
             self._wgrad(L[lb], View(g_tb), 96, View(ta), 96, 0, None, 0, 96, N, h, w, t3)
-            g_ta = self.act("g_" + tag + "a", N, h, w, 96)
+            g_ta = self.grad("g_" + tag + "a", N, h, w, 96)
             dgrad(lb, g_tb, 96, N, h, w, rt3, 96, View(g_ta), mask=View(ta))
             if c_up + c_skip <= 96:
                 self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, View(skip), c_skip, c_up + c_skip_real, N, h, w, t3)
@@ -386,9 +391,9 @@ class NetPlan:
                 self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, None, 0, c_up, N, h, w, t3, c_off=0, with_bias=True)
                 self._wgrad(L[la], View(g_ta), 96, None, 0, 0, View(skip), c_skip, c_skip_real, N, h, w, t3, c_off=c_up, with_bias=False)
             Mx = c_up + (c_skip if need_skip_grad else 0)
-            dxs = self.act("dxs_" + tag, N, h, w, Mx)
+            dxs = self.grad("dxs_" + tag, N, h, w, Mx)
             dgrad(la, g_ta, 96, N, h, w, rt3, Mx, View(dxs))
-            g_up = self.act("g_up_" + tag, N, h // 2, w // 2, c_up)
+            g_up = self.grad("g_up_" + tag, N, h // 2, w // 2, c_up)
             b.append(Op("upsum_bwd", dict(src=View(dxs), mask=View(up_src), dst=View(g_up), N=N, H=h // 2, W=w // 2, C=c_up)))
             return g_up, (View(dxs, c_up) if need_skip_grad else None)
 
@@ -402,9 +407,9 @@ class NetPlan:
             """backward of conv(pool(act_prev)): wgrad, then data gradient w.r.t. `src` (= pooled tensor), plus the
             decoder's skip gradient, routed through the max-pool to the pre-activation of the previous conv."""
             self._wgrad(L[lname], View(g_out), 48, View(src), 48, 0, None, 0, 48, N, h, w, t3)
-            g_p = self.act("g_p_" + tag, N, h, w, 48)
+            g_p = self.grad("g_p_" + tag, N, h, w, 48)
             dgrad(lname, g_out, 48, N, h, w, rt3, 48, View(g_p), add=skip_add)
-            g_prev = self.act("g_e_" + tag, N, 2 * h, 2 * w, 48)
+            g_prev = self.grad("g_e_" + tag, N, 2 * h, 2 * w, 48)
             b.append(Op("pool_bwd", dict(act=View(act_prev), dpool=View(g_p), dz=View(g_prev), N=N, H=2 * h, W=2 * w, C=48, shifted=int(bs))))
             return g_prev
 
@@ -415,7 +420,7 @@ class NetPlan:
         g_e1 = enc_bwd("encode_block_2.0", g_e2, p1, H // 2, W // 2, "2", sk_p1, e1)
         # encode_block_1.2 (e0 -> e1) and encode_block_1.0 (x16 -> e0)
         self._wgrad(L["encode_block_1.2"], View(g_e1), 48, View(e0), 48, 0, None, 0, 48, N, H, W, t3)
-        g_e0 = self.act("g_e0", N, H, W, 48)
+        g_e0 = self.grad("g_e0", N, H, W, 48)
         dgrad("encode_block_1.2", g_e1, 48, N, H, W, rt3, 48, View(g_e0), mask=View(e0))
         self._wgrad(L["encode_block_1.0"], View(g_e0), 48, None, 0, 0, View(x16), 16, C, N, H, W, t3)
         # shared scratch for the weight-gradient slabs

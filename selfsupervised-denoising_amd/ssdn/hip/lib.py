@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32), ("H", i32), ("W", i32),
                 ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("w", vp), ("M", i32), ("Mpad", i32),
                 ("Ktot", i32), ("bias", vp), ("act", i32), ("mask", View), ("add", View), ("dst", View), ("dst32", vp),
-                ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32)]
+                ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32), ("bf16", i32)]
 
 
 class PoolArgs(C.Structure):
