@@ -157,7 +157,7 @@ typedef struct ssdn_unrot_args {
 /* ---- SSDN_OP_WGRAD --------------------------------------------------------------------------
  * replaces: autograd's conv weight/bias gradient.  dz is bf16, IN is fp16 (converted to bf16 while it is staged in
  * LDS; products are exact in the fp32 accumulator).  Every workgroup s < nslabs reduces its share of pixels into
- *   slab[s][t][m][k] = sum_pixels dz(n,y,x,m) * IN(n, y+dy[t], x+dx[t], k)      (fp32, [nslabs][ntaps][Mpad][Kpad])
+ *   slab[s][t][m][k] = sum_pixels dz(n,y,x,m) * IN(n, y+dy[t], x+dx[t], coff[t]+k)   (fp32, [nslabs][ntaps][Mpad][Kpad])
  *   bslab[s][m]      = sum_pixels dz(n,y,x,m)
  * IN as in SSDN_OP_CONV.  Deterministic: fixed pixel->workgroup assignment, SSDN_OP_WREDUCE sums slabs in order. */
 typedef struct ssdn_wgrad_args {
@@ -169,7 +169,8 @@ typedef struct ssdn_wgrad_args {
     int32_t ntaps;
     int32_t dy[SSDN_MAX_TAPS];
     int32_t dx[SSDN_MAX_TAPS];
-    int32_t M, Mpad, Ktot, Kpad;
+    int32_t coff[SSDN_MAX_TAPS]; /* channel offset of tap t inside IN: lets the "taps" of a 1x1 layer be channel blocks */
+    int32_t M, Mpad, Ktot, Kpad; /* Ktot = channels staged; every tap covers channels [coff[t], coff[t]+Kpad) */
     float* slab;
     float* bslab;
     int32_t nslabs;
@@ -179,7 +180,9 @@ typedef struct ssdn_wgrad_args {
 /* ---- SSDN_OP_WREDUCE ------------------------------------------------------------------------
  * gw[m][cin][ky][kx] (fp32 OIHW, the checkpoint layout) = inv_scale * sum_s slab[s][t][m][k(cin)],
  * gb[m] = inv_scale * sum_s bslab[s][m];  k(cin) = cin (cin < c0) else c0 + (cin - c0) i.e. padding removed:
- * real input channels are [0,c0) and [c0, c0+c1_real).  inv_scale is read from device memory (loss-scale word). */
+ * real input channels are [0,c0) and [c0, c0+c1_real).  inv_scale is read from device memory (loss-scale word).
+ * Slabs are summed in a fixed order (groups of 32 in index order, then the groups in order): bit-reproducible.
+ * NOTE: the slab buffer is used as scratch (partial sums are written back into it). */
 typedef struct ssdn_wreduce_args {
     const float* slab;
     const float* bslab;
@@ -187,6 +190,7 @@ typedef struct ssdn_wreduce_args {
     int32_t cin;      /* real input channels covered by this slab (k < cin are real, the rest is padding) */
     int32_t cin_full; /* input channels of the whole weight tensor (row length of gw) */
     int32_t m_off, c_off; /* this slab is the block gw[m_off.., c_off..] (the 1x1 head layers are computed in blocks) */
+    int32_t tapblock;     /* 1: the slab's "taps" are channel blocks of a 1x1 layer: input channel = c_off + t*Kpad + k */
     float* gw;
     float* gb; /* may be NULL (bias gradient is produced by one block column only) */
     const float* inv_scale; /* device scalar, may be NULL (=1) */

@@ -194,20 +194,25 @@ class Interp:
         out[..., :C] = gg.permute(0, 2, 3, 1)
         self.store(dst, cpad, out)
 
-    def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn):
+    def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, coff, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn):
         x = _r16(self._gather(src0, src1, c0, c1, up0, N, H, W), self.fp16, "bf16")   # staged as bf16 on the device
         g = self.view(dz, M)
         self.slab = torch.zeros(len(taps), Mpad, Kpad)
         for t, (dy, dx) in enumerate(taps):
-            self.slab[t, :M, :Ktot] = torch.einsum("nhwm,nhwk->mk", g, self._shift(x, dy, dx))
+            kw = min(Kpad, Ktot - coff[t])
+            self.slab[t, :M, :kw] = torch.einsum("nhwm,nhwk->mk", g, self._shift(x, dy, dx)[..., coff[t]:coff[t] + kw])
         self.bslab = torch.zeros(Mpad)
         self.bslab[:M] = g.sum((0, 1, 2))
 
-    def op_wreduce(self, layer, nslabs, ntaps, M, Mpad, Kpad, cin, cin_full, m_off, c_off, with_bias):
+    def op_wreduce(self, layer, nslabs, ntaps, M, Mpad, Kpad, cin, cin_full, m_off, c_off, with_bias, tapblock=0):
         l = self.L[layer]
         base = self.plan.param_base
         gw = self.grads[base + l.w_off: base + l.w_off + l.M * l.cin * l.ntaps].reshape(l.M, l.cin, l.ntaps)
         assert cin_full == l.cin
-        gw[m_off:m_off + M, c_off:c_off + cin, :] = self.slab[:, :M, :cin].permute(1, 2, 0) / self.scale
+        if tapblock:     # the slab's taps are channel blocks of a 1x1 layer
+            blk = self.slab[:, :M, :].permute(1, 0, 2).reshape(M, ntaps * Kpad)[:, :cin]
+            gw[m_off:m_off + M, c_off:c_off + cin, 0] = blk / self.scale
+        else:
+            gw[m_off:m_off + M, c_off:c_off + cin, :] = self.slab[:, :M, :cin].permute(1, 2, 0) / self.scale
         if with_bias:
             self.grads[base + l.b_off + m_off: base + l.b_off + m_off + M] = self.bslab[:M] / self.scale

@@ -51,12 +51,13 @@ static inline unsigned magic_of(unsigned d) { return (unsigned)((0x100000000ull 
 struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
     unsigned mg_cc8;        // magic reciprocal of cc8
+    unsigned mg_ntaps;      // magic reciprocal of ntaps
     int lg;                 // log2(threads cooperating on one pixel when staging the tile)
     int cc8;                // 16-B chunks per pixel per channel chunk (= kc/8)
     int m_base;             // first output channel of this launch (multiple of 32)
 };
 
-#define CONV_NW 9  // weight-slice prefetch registers per thread (16 B each): covers MT*32 rows x kc<=192 channels
+#define CONV_NW 3  // 16-B registers per thread per prefetched weight slice: MT*32 rows x kc channels <= 3*256*8 halves (MT=3: kc<=64)
 
 template <bool BF>
 static __device__ __forceinline__ f32x16 mma(half8 av, half8 bv, f32x16 c) {
@@ -69,7 +70,7 @@ static __device__ __forceinline__ f32x16 mma(half8 av, half8 bv, f32x16 c) {
 // BF = false: fp16 operands / fp16 output (forward);  BF = true: bf16 operands / bf16 output (data gradient).
 // Tiles are moved through LDS as raw 16-bit words, so only the MFMA opcode and the epilogue conversions differ.
 template <int MT, bool BF>
-__global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux x) {
+__global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, ConvAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, a.kc);
     char* tile = smem;
@@ -113,6 +114,7 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux
     const h16* s1 = (const h16*)a.src1.p;
     const h16* wp = (const h16*)a.w;
 
+    const int nsteps_ = nchunks * a.ntaps;
     // weight-slice prefetch: element e = tid + 256*i  ->  row e / cc8, 16-B chunk e % cc8
     const int wtotal = MT * 32 * x.cc8;
     int w_goff[CONV_NW], w_loff[CONV_NW];
@@ -124,17 +126,18 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux
         w_goff[i] = e < wtotal ? ((x.m_base + m) * a.Ktot + cc * 8) : -1;
         w_loff[i] = m * g.WSTR + cc * 16;
     }
-    half8 wreg[CONV_NW];
-    auto w_issue = [&](int ch, int t) {
+    half8 wrA[CONV_NW], wrB[CONV_NW];   // two register sets: the weight stream runs TWO steps ahead of the MFMA work
+    auto w_issue = [&](half8 (&wr)[CONV_NW], int step) {
+        const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
         const h16* base = wp + (long long)t * a.Mpad * a.Ktot + ch * a.kc;
 #pragma unroll
         for (int i = 0; i < CONV_NW; ++i)
-            if (w_goff[i] >= 0) wreg[i] = ld_h8(base + w_goff[i]);
+            if (w_goff[i] >= 0) wr[i] = ld_h8(base + w_goff[i]);
     };
-    auto w_commit = [&](char* buf) {
+    auto w_commit = [&](half8 (&wr)[CONV_NW], char* buf) {
 #pragma unroll
         for (int i = 0; i < CONV_NW; ++i)
-            if (w_goff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wreg[i];
+            if (w_goff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wr[i];
     };
     auto stage_tile = [&](int ch) {
         if (sub < x.cc8) {
@@ -166,46 +169,55 @@ __global__ __launch_bounds__(CONV_THREADS) void k_conv(ssdn_conv_args a, ConvAux
             }
         }
     };
-
-    // ---- software pipeline over (channel chunk, tap) steps: weights of step s+1 are fetched into registers while
-    //      step s runs on the matrix cores, committed to the other LDS buffer afterwards; one barrier per step ----
-    const int nsteps = nchunks * a.ntaps;
-    w_issue(0, 0);
-    stage_tile(0);
-    w_commit(wl0);
-    __syncthreads();
-    int ch = 0, t = 0;
-    for (int step = 0; step < nsteps; ++step) {
-        int nch = ch, nt_ = t + 1;
-        if (nt_ == a.ntaps) { nt_ = 0; ++nch; }
-        const bool more = step + 1 < nsteps;
-        if (more) w_issue(nch, nt_);
-        {
-            const char* wl = wl0 + (step & 1) * wbuf_bytes;
-            const int toff = (a.dy[t] * g.HW + a.dx[t]) * g.PSTR;
-            const char* b0p = tile + bbase[0] + toff;
-            const char* b1p = tile + bbase[1] + toff;
-            const char* ap = wl + abase;
-            for (int s = 0; s < a.kc; s += 16) {
-                half8 b0 = *reinterpret_cast<const half8*>(b0p + s * 2);
-                half8 b1 = *reinterpret_cast<const half8*>(b1p + s * 2);
+    auto compute = [&](const char* wl, int step) {
+        const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
+        (void)ch;
+        const int toff = (a.dy[t] * g.HW + a.dx[t]) * g.PSTR;
+        const char* b0p = tile + bbase[0] + toff;
+        const char* b1p = tile + bbase[1] + toff;
+        const char* ap = wl + abase;
+        for (int s = 0; s < a.kc; s += 16) {
+            half8 b0 = *reinterpret_cast<const half8*>(b0p + s * 2);
+            half8 b1 = *reinterpret_cast<const half8*>(b1p + s * 2);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    half8 av = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR + s * 2);
-                    acc[mt][0] = mma<BF>(av, b0, acc[mt][0]);
-                    acc[mt][1] = mma<BF>(av, b1, acc[mt][1]);
-                }
+            for (int mt = 0; mt < MT; ++mt) {
+                half8 av = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR + s * 2);
+                acc[mt][0] = mma<BF>(av, b0, acc[mt][0]);
+                acc[mt][1] = mma<BF>(av, b1, acc[mt][1]);
             }
         }
-        if (more) {
-            if (nch != ch) {           // next step starts a new channel chunk: the tile is re-staged once everyone is done
+    };
+    // after the MFMA work of `step`: make step+1 runnable (re-stage the tile if it starts a new channel chunk, move its
+    // prefetched weights registers -> idle LDS buffer), then ONE barrier
+    auto advance = [&](half8 (&wr_next)[CONV_NW], char* buf_next, int step) {
+        if (step + 1 < nsteps_) {
+            const int ch = fdiv(step, x.mg_ntaps), nch = fdiv(step + 1, x.mg_ntaps);
+            if (nch != ch) {
                 __syncthreads();
                 stage_tile(nch);
             }
-            w_commit(wl0 + ((step + 1) & 1) * wbuf_bytes);
+            w_commit(wr_next, buf_next);
         }
         __syncthreads();
-        ch = nch; t = nt_;
+    };
+
+    // ---- software pipeline over (channel chunk, tap) steps.  Step s reads LDS buffer s&1; the weights of step s+1 sit in
+    //      registers (issued during step s-1) and those of step s+2 are issued now: two steps of MFMA work hide the
+    //      L2 latency of the weight stream.  One barrier per step. ----
+    char* wl1 = wl0 + wbuf_bytes;
+    w_issue(wrA, 0);
+    if (nsteps_ > 1) w_issue(wrB, 1);
+    stage_tile(0);
+    w_commit(wrA, wl0);
+    __syncthreads();
+    for (int step = 0; step < nsteps_; step += 2) {
+        if (step + 2 < nsteps_) w_issue(wrA, step + 2);
+        compute(wl0, step);
+        advance(wrB, wl1, step);
+        if (step + 1 >= nsteps_) break;
+        if (step + 3 < nsteps_) w_issue(wrB, step + 3);
+        compute(wl1, step + 1);
+        advance(wrA, wl0, step + 1);
     }
 
     // ---- epilogue: D row = 8*(r>>2) + 4*(lane>>5) + (r&3)  (output channel), D col = lane&31 (pixel) -------------
@@ -271,6 +283,12 @@ static int conv_validate(const ssdn_conv_args* a) {
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 15)) return ssdn_set_error("conv: Ktot must equal c0+c1 and be a multiple of 16");
     if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("conv: source channel counts must be multiples of 8");
     if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc || a->kc > 192) return ssdn_set_error("conv: kc must be a multiple of 16 (<= 192) dividing Ktot");
+    {
+        int mt = a->Mpad / 32;
+        mt = mt > 3 ? 3 : mt;
+        if (mt * 32 * (a->kc / 8) > CONV_NW * CONV_THREADS)
+            return ssdn_set_error("conv: weight slice %d x %d exceeds the prefetch registers (kc*MT <= %d)", mt * 32, a->kc, CONV_NW * CONV_THREADS / 4);
+    }
     if ((a->Mpad & 31) || a->M > a->Mpad) return ssdn_set_error("conv: Mpad must be a multiple of 32 and >= M");
     if (!a->dst32 && (a->M & 3)) return ssdn_set_error("conv: fp16 output needs M %% 4 == 0");
     if (a->up0 && ((a->H | a->W) & 1)) return ssdn_set_error("conv: upsampled source needs even H, W");
@@ -322,6 +340,7 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     x.mg_hh = magic_of(g.HH);
     x.cc8 = a->kc / 8;
     x.mg_cc8 = magic_of(x.cc8);
+    x.mg_ntaps = magic_of(a->ntaps);
     x.lg = 0;
     while ((1 << x.lg) < x.cc8) ++x.lg;
     if (x.lg > 8) return ssdn_set_error("conv: kc too large");

@@ -321,9 +321,30 @@ int launch_wpack(const ssdn_wpack_args* a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // WREDUCE: ordered sum of the per-workgroup weight-gradient slabs -> fp32 OIHW gradient
 // ------------------------------------------------------------------------------------------------
-__global__ void k_wreduce(ssdn_wreduce_args a) {
-    // one thread per slab element in SLAB order (k fastest): every slab is read with fully coalesced 4-byte loads,
-    // slabs are summed in index order (deterministic), 8 independent loads in flight per thread.
+#define WR_GROUP 32
+// stage 1: float4 per thread, 32 slabs per group, partial sum written back over the group's first slab
+__global__ void k_wreduce_partial(float* slab, long long stride, int nslabs) {
+    long long i4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i4 * 4 >= stride) return;
+    int s0 = blockIdx.y * WR_GROUP;
+    int s1 = s0 + WR_GROUP < nslabs ? s0 + WR_GROUP : nslabs;
+    float4* p = reinterpret_cast<float4*>(slab + i4 * 4);
+    const long long st4 = stride / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    int s = s0;
+    for (; s + 8 <= s1; s += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * st4];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+    }
+    for (; s < s1; ++s) { float4 v = p[(long long)s * st4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+    p[(long long)s0 * st4] = acc;
+}
+// stage 2 (or the only stage when nslabs <= 32): one thread per slab element in SLAB order (k fastest), slabs
+// s = 0, step, 2*step, ... summed in order; writes the OIHW gradient.
+__global__ void k_wreduce(ssdn_wreduce_args a, int step) {
     long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long stride = (long long)a.ntaps * a.Mpad * a.Kpad;
     float inv = a.inv_scale ? *a.inv_scale : 1.f;
@@ -331,19 +352,14 @@ __global__ void k_wreduce(ssdn_wreduce_args a) {
         int k = idx % a.Kpad;
         int m = (idx / a.Kpad) % a.Mpad;
         int t = idx / ((long long)a.Kpad * a.Mpad);
-        if (k < a.cin && m < a.M) {
+        int ci = a.tapblock ? t * a.Kpad + k : k;
+        if (k < (a.tapblock ? a.Kpad : a.cin) && ci < a.cin && m < a.M) {
             const float* p = a.slab + idx;
             float acc = 0.f;
-            int s = 0;
-            for (; s + 8 <= a.nslabs; s += 8) {
-                float v[8];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * stride];
-#pragma unroll
-                for (int u = 0; u < 8; ++u) acc += v[u];
-            }
-            for (; s < a.nslabs; ++s) acc += p[(long long)s * stride];
-            a.gw[((long long)(a.m_off + m) * a.cin_full + a.c_off + k) * a.ntaps + t] = acc * inv;
+            for (int s = 0; s < a.nslabs; s += step) acc += p[(long long)s * stride];
+            long long o = a.tapblock ? ((long long)(a.m_off + m) * a.cin_full + a.c_off + ci)
+                                     : ((long long)(a.m_off + m) * a.cin_full + a.c_off + k) * a.ntaps + t;
+            a.gw[o] = acc * inv;
         }
     } else if (idx < stride + a.M && a.gb) {
         int m = idx - stride;
@@ -353,8 +369,15 @@ __global__ void k_wreduce(ssdn_wreduce_args a) {
     }
 }
 int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s) {
-    long long n = (long long)a->ntaps * a->Mpad * a->Kpad + a->M;
-    hipLaunchKernelGGL(k_wreduce, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    long long stride = (long long)a->ntaps * a->Mpad * a->Kpad;
+    int step = 1;
+    if (a->nslabs > WR_GROUP) {
+        int groups = (a->nslabs + WR_GROUP - 1) / WR_GROUP;
+        hipLaunchKernelGGL(k_wreduce_partial, dim3(ew_grid(stride / 4), groups), dim3(EW_BLOCK), 0, s, (float*)a->slab, stride, a->nslabs);
+        step = WR_GROUP;
+    }
+    long long n = stride + a->M;
+    hipLaunchKernelGGL(k_wreduce, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a, step);
     return 0;
 }
 

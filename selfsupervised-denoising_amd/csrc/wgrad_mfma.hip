@@ -50,7 +50,9 @@ static __host__ __device__ inline WgGeom wg_geom(const ssdn_wgrad_args& a) {
     g.HH = g.TH - mny + mxy;
     g.HW = g.TW - mnx + mxx;
     g.NP = g.TN * g.HH * g.HW;
-    g.PSTR = a.Kpad * 2 + 16;  // Kpad >= Ktot: the pad channels are never staged, only (harmlessly) read
+    int kmax = a.Ktot;          // channels a transpose-read may touch: staged ones + the (harmless, never used) padding
+    for (int t = 0; t < a.ntaps; ++t) kmax = a.coff[t] + a.Kpad > kmax ? a.coff[t] + a.Kpad : kmax;
+    g.PSTR = kmax * 2 + 16;
     g.DSTR = a.Mpad * 2 + 16;
     g.tiles_x = (a.W + g.TW - 1) / g.TW;
     g.tiles_y = (a.H + g.TH - 1) / g.TH;
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
                 if (ct_bias[j]) {
                     bf = ones;
                 } else {
-                    const int toff = (a.dy[ct_tap[j]] * g.HW + a.dx[ct_tap[j]]) * g.PSTR + (ct_nt[j] * 32 + mh * 16) * 2;
+                    const int toff = (a.dy[ct_tap[j]] * g.HW + a.dx[ct_tap[j]]) * g.PSTR + (a.coff[ct_tap[j]] + ct_nt[j] * 32 + mh * 16) * 2;
                     bf = cat8(tr16(xt + xofs[0] + toff), tr16(xt + xofs[1] + toff));
                 }
 #pragma unroll
@@ -224,7 +226,9 @@ static int wgrad_validate(const ssdn_wgrad_args* a) {
     if (a->ltw + a->lth + a->ltn > 8 || a->ltw + a->lth + a->ltn < 4) return ssdn_set_error("wgrad: tile must have 16..256 pixels");
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 7)) return ssdn_set_error("wgrad: Ktot must equal c0+c1 (multiple of 8)");
     if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("wgrad: source channel counts must be multiples of 8");
-    if ((a->Kpad & 31) || a->Kpad < a->Ktot || a->Kpad > 96) return ssdn_set_error("wgrad: Kpad must be 32/64/96 and >= Ktot");
+    if ((a->Kpad & 31) || a->Kpad > 96) return ssdn_set_error("wgrad: Kpad must be 32/64/96");
+    for (int t = 0; t < a->ntaps; ++t)
+        if (a->coff[t] < 0 || (a->coff[t] & 15) || a->coff[t] >= a->Ktot) return ssdn_set_error("wgrad: bad channel offset of tap %d", t);
     if ((a->Mpad & 31) || a->Mpad > 96 || a->M > a->Mpad || (a->M & 7)) return ssdn_set_error("wgrad: Mpad must be 32/64/96, M %% 8 == 0");
     if (a->nslabs < 1) return ssdn_set_error("wgrad: nslabs < 1");
     return 0;

@@ -117,6 +117,7 @@ class DeviceNet:
             s.ntaps = len(a["taps"])
             for i, (dy, dx) in enumerate(a["taps"]):
                 s.dy[i], s.dx[i] = dy, dx
+                s.coff[i] = a["coff"][i]
             s.M, s.Mpad, s.Ktot, s.Kpad = a["M"], a["Mpad"], a["Ktot"], a["Kpad"]
             s.slab, s.bslab = _ptr(self.t[P + "slab"]), _ptr(self.t[P + "bslab"])
             s.nslabs = a["nslabs"]
@@ -127,7 +128,7 @@ class DeviceNet:
         if op.type == "wreduce":
             l = self._layer(a["layer"])
             return op.type, L.WreduceArgs(_ptr(self.t[P + "slab"]), _ptr(self.t[P + "bslab"]), a["nslabs"], a["ntaps"], a["M"],
-                                          a["Mpad"], a["Kpad"], a["cin"], a["cin_full"], a["m_off"], a["c_off"],
+                                          a["Mpad"], a["Kpad"], a["cin"], a["cin_full"], a["m_off"], a["c_off"], a["tapblock"],
                                           self._gp(l.w_off), self._gp(l.b_off) if a["with_bias"] else None,
                                           _ptr(self.t[P + "scale"], 4))
         if op.type == "wpack":

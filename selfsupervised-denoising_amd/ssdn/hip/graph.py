@@ -99,7 +99,7 @@ def net_layers(in_channels: int, out_channels: int, blindspot: bool) -> List[Lay
         Layer("decode_block_3.2", 96, 96, 3, 96, 0, 0),
         Layer("decode_block_2.0", 96, 144, 3, 96, 48, 48),
         Layer("decode_block_2.2", 96, 96, 3, 96, 0, 0),
-        Layer("decode_block_1.0", 96, 96 + c, 3, 96, cpad, c),
+        Layer("decode_block_1.0", 96, 96 + c, 3, 96, 2 * cpad, c),      # K = 96 + 32: two channel chunks of 64
         Layer("decode_block_1.2", 96, 96, 3, 96, 0, 0),
         Layer("output_block.0", nin, nin, 1, nin, 0, 0),
         Layer("output_block.2", 96, nin, 1, nin, 0, 0),
@@ -245,23 +245,29 @@ class NetPlan:
                                    dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"))))
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
-               m_off=0, c_off=0, with_bias=True):
+               m_off=0, c_off=0, with_bias=True, cblocks=None):
         """One SSDN_OP_WGRAD + SSDN_OP_WREDUCE pair covering output channels [m_off, m_off+M) x input channels
-        [c_off, c_off+cin_real) of `layer` (M <= 96, Ktot <= 96)."""
+        [c_off, c_off+cin_real) of `layer` (M <= 96; Ktot <= 96 per tap).
+        cblocks (1x1 layers only): list of channel offsets -- the kernel's "taps" become 96-channel blocks of the input,
+        so one launch covers M x len(cblocks)*96 weights."""
         Ktot = c0 + c1
-        Kpad = ceil_to(Ktot, 32)
+        Kpad = ceil_to(Ktot, 32) if cblocks is None else 96
+        coff = [0] * len(taps) if cblocks is None else list(cblocks)
+        if cblocks is not None:
+            taps = [(0, 0)] * len(cblocks)
         Mpad = ceil_to(Mz, 32)
-        (ltw, lth, ltn), ntiles = choose_wgrad_tile(N, H, W, taps, Kpad, Mpad)
+        (ltw, lth, ltn), ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad)
         nslabs = max(1, min(ntiles, self.cus))
         ntaps = len(taps)
         self.max_slab = max(self.max_slab, nslabs * ntaps * Mpad * Kpad)
         self.max_bslab = max(self.max_bslab, nslabs * Mpad)
         M_real = min(Mz, layer.M - m_off)
         self.bwd.append(Op("wgrad", dict(layer=layer.name, dz=dz, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
-                                         taps=list(taps), M=Mz, Mpad=Mpad, Ktot=Ktot, Kpad=Kpad, nslabs=nslabs,
+                                         taps=list(taps), coff=coff, M=Mz, Mpad=Mpad, Ktot=Ktot, Kpad=Kpad, nslabs=nslabs,
                                          ltw=ltw, lth=lth, ltn=ltn)))
         self.bwd.append(Op("wreduce", dict(layer=layer.name, nslabs=nslabs, ntaps=ntaps, M=M_real, Mpad=Mpad, Kpad=Kpad,
-                                           cin=cin_real, cin_full=layer.cin, m_off=m_off, c_off=c_off, with_bias=with_bias)))
+                                           cin=cin_real, cin_full=layer.cin, m_off=m_off, c_off=c_off, with_bias=with_bias,
+                                           tapblock=int(cblocks is not None))))
 
     # ---- construction --------------------------------------------------------------------------------------
     def _build(self):
@@ -273,8 +279,8 @@ class NetPlan:
 
         # ---------------- forward ----------------
         self.T("in32", "f32", (B, C, H, W))
-        x16 = self.act("x16", N, H, W, 16)
-        f.append(Op("pack_input", dict(src=self.prefix + "in32", dst=View(x16), B=B, C=C, H=H, W=W, R=self.R, cpad=16)))
+        x16 = self.act("x16", N, H, W, 32)     # C real channels, zero padded to 32 (the first layer reads a 16-channel view)
+        f.append(Op("pack_input", dict(src=self.prefix + "in32", dst=View(x16), B=B, C=C, H=H, W=W, R=self.R, cpad=32)))
 
         def enc(name, lname, src, cin_slots, h, w):
             t = self.act(name, N, h, w, 48)
@@ -310,7 +316,7 @@ class NetPlan:
         d4a, d4b = dec("d4a", "d4b", "decode_block_4.0", "decode_block_4.2", d5b, 96, p3, 48, H // 8, W // 8)
         d3a, d3b = dec("d3a", "d3b", "decode_block_3.0", "decode_block_3.2", d4b, 96, p2, 48, H // 4, W // 4)
         d2a, d2b = dec("d2a", "d2b", "decode_block_2.0", "decode_block_2.2", d3b, 96, p1, 48, H // 2, W // 2)
-        d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W)
+        d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 32, H, W)
 
         nin = 384 if bs else 96
         if bs:
@@ -362,16 +368,14 @@ class NetPlan:
         dgrad("output_block.4", gz, 16, B, H, W, TAPS_1x1, 96, View(g_nb), mask=View(nb))
         # output_block.2 : nin -> 96
         lo2 = L["output_block.2"]
-        for ci in range(0, nin, 96):
-            self._wgrad(lo2, View(g_nb), 96, View(na, ci), 96, 0, None, 0, 96, B, H, W, TAPS_1x1, c_off=ci, with_bias=(ci == 0))
+        blocks = list(range(0, nin, 96))
+        self._wgrad(lo2, View(g_nb), 96, View(na), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, cblocks=blocks)
         g_na = self.grad("g_na", B, H, W, nin)
         dgrad("output_block.2", g_nb, 96, B, H, W, TAPS_1x1, nin, View(g_na), mask=View(na))
         # output_block.0 : nin -> nin
         lo0 = L["output_block.0"]
         for mi in range(0, nin, 96):
-            for ci in range(0, nin, 96):
-                self._wgrad(lo0, View(g_na, mi), 96, View(head_in, ci), 96, 0, None, 0, 96, B, H, W, TAPS_1x1,
-                            m_off=mi, c_off=ci, with_bias=(ci == 0))
+            self._wgrad(lo0, View(g_na, mi), 96, View(head_in), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, m_off=mi, cblocks=blocks)
         g_d1b = self.grad("g_d1b", N, H, W, 96)
         if bs:
             g_u = self.grad("g_u", B, H, W, 384)
@@ -397,7 +401,7 @@ class NetPlan:
             b.append(Op("upsum_bwd", dict(src=View(dxs), mask=View(up_src), dst=View(g_up), N=N, H=h // 2, W=w // 2, C=c_up)))
             return g_up, (View(dxs, c_up) if need_skip_grad else None)
 
-        g_d2b, _ = dec_bwd("decode_block_1.0", "decode_block_1.2", d1a, d1b, g_d1b, d2b, 96, x16, 16, C, H, W, "d1", need_skip_grad=False)
+        g_d2b, _ = dec_bwd("decode_block_1.0", "decode_block_1.2", d1a, d1b, g_d1b, d2b, 96, x16, 32, C, H, W, "d1", need_skip_grad=False)
         g_d3b, sk_p1 = dec_bwd("decode_block_2.0", "decode_block_2.2", d2a, d2b, g_d2b, d3b, 96, p1, 48, 48, H // 2, W // 2, "d2")
         g_d4b, sk_p2 = dec_bwd("decode_block_3.0", "decode_block_3.2", d3a, d3b, g_d3b, d4b, 96, p2, 48, 48, H // 4, W // 4, "d3")
         g_d5b, sk_p3 = dec_bwd("decode_block_4.0", "decode_block_4.2", d4a, d4b, g_d4b, d5b, 96, p3, 48, 48, H // 8, W // 8, "d4")

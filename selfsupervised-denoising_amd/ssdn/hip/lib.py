@@ -54,14 +54,15 @@ class UnrotArgs(C.Structure):
 
 class WgradArgs(C.Structure):
     _fields_ = [("dz", View), ("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32),
-                ("H", i32), ("W", i32), ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("M", i32),
-                ("Mpad", i32), ("Ktot", i32), ("Kpad", i32), ("slab", vp), ("bslab", vp), ("nslabs", i32), ("ltw", i32),
+                ("H", i32), ("W", i32), ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("coff", i32 * MAX_TAPS),
+                ("M", i32), ("Mpad", i32), ("Ktot", i32), ("Kpad", i32), ("slab", vp), ("bslab", vp), ("nslabs", i32), ("ltw", i32),
                 ("lth", i32), ("ltn", i32)]
 
 
 class WreduceArgs(C.Structure):
     _fields_ = [("slab", vp), ("bslab", vp), ("nslabs", i32), ("ntaps", i32), ("M", i32), ("Mpad", i32), ("Kpad", i32),
-                ("cin", i32), ("cin_full", i32), ("m_off", i32), ("c_off", i32), ("gw", vp), ("gb", vp), ("inv_scale", vp)]
+                ("cin", i32), ("cin_full", i32), ("m_off", i32), ("c_off", i32), ("tapblock", i32), ("gw", vp), ("gb", vp),
+                ("inv_scale", vp)]
 
 
 class WpackArgs(C.Structure):

@@ -1,9 +1,6 @@
 """GPU: the drop-in `Denoiser` façade end to end (run_pipeline -> backward -> fused Adam) against
 (a) the golden training trajectories generated from the reference (tests/golden/g_train_*.npz) and
-(b) the oracle trainer run side by side on the host (full tensors).
-fp16 activations vs the fp32 reference: losses within 1e-2 relative; parameter UPDATES (what Adam did in 3 steps) must point
-the same way: cosine >= 0.9 per network (Adam's first steps are ~lr*sign(g), so an element whose tiny gradient flips sign
-under fp16 noise moves the opposite way -- the cosine, not an element-wise bound, is the meaningful statement)."""
+(b) the oracle trainer run side by side on the host (full tensors), step by step from identical states."""
 import os
 
 import numpy as np
@@ -29,8 +26,39 @@ def make_denoiser(alg, style, mode, ch):
     return Denoiser(cfg, device="cuda:0")
 
 
+def _flat_of(d, net_list, tr):
+    """oracle trainer state -> the Denoiser's flat parameter layout"""
+    f = torch.zeros(d.flat.numel())
+    for net, base, cur in net_list:
+        for l in net.layers:
+            f[base + l.w_off: base + l.w_off + l.M * l.cin * l.k * l.k] = cur[l.name + ".weight"].detach().reshape(-1)
+            f[base + l.b_off: base + l.b_off + l.M] = cur[l.name + ".bias"].detach()
+    if tr.est is not None:
+        f[d._n_main + d._n_sig] = float(tr.est.detach().reshape(-1)[0])
+    return f
+
+
+def _flat_grad_of(d, net_list, tr):
+    f = torch.zeros(d.flat.numel())
+    for net, base, cur in net_list:
+        for l in net.layers:
+            f[base + l.w_off: base + l.w_off + l.M * l.cin * l.k * l.k] = cur[l.name + ".weight"].grad.reshape(-1)
+            f[base + l.b_off: base + l.b_off + l.M] = cur[l.name + ".bias"].grad
+    if tr.est is not None:
+        f[d._n_main + d._n_sig] = float(tr.est.grad.reshape(-1)[0])
+    return f
+
+
 @pytest.mark.parametrize("tag,alg,style,mode,ch", TRAIN_CASES)
 def test_training_trajectory(golden_dir, tag, alg, style, mode, ch):
+    """Three optimisation steps next to the oracle trainer (which tests/test_oracle_golden pins to the reference's
+    trajectory fixtures g_train_*).  Every step is checked from the SAME starting point -- the oracle's current weights
+    are loaded into the device first -- because these fixtures sit in a very steep part of the loss surface (the loss
+    halves per 1e-4 step; measured: a 2.5% sign disagreement on near-zero gradient elements changes the next loss by
+    12% for poisson/const), so a free-running comparison would test chaos, not kernels.  Per step:
+      loss            1e-2 relative (vs oracle AND vs the reference's golden value)
+      gradient        cosine >= 0.985, sign agreement >= 0.95 over all 1.27M (+1.1M) parameters
+      Adam update     cosine >= 0.9 with the oracle's update, |update| <= lr everywhere."""
     from ssdn.denoiser import Denoiser
     from ssdn.datasets import NoisyDataset
     from ssdn.params import PipelineOutput
@@ -40,49 +68,65 @@ def test_training_trajectory(golden_dir, tag, alg, style, mode, ch):
     p0 = R.make_params(ch, cout, bs, seed=5)
     sp0 = R.make_params(ch, 1, False, seed=6) if (mode == "var" and alg == "ssdn") else None
     d = make_denoiser(alg, style, mode, ch)
-    d.get_model(Denoiser.MODEL, False).load_state_dict(R.reference_state_dict(p0))
-    if sp0 is not None:
-        d.get_model(Denoiser.SIGMA_ESTIMATOR, False).load_state_dict(R.reference_state_dict(sp0))
-    d.mark_dirty()
     d.train()
     tr = R.CpuTrainer(alg, ch, style, mode, params={k: v.clone() for k, v in p0.items()},
                       sigma_params={k: v.clone() for k, v in sp0.items()} if sp0 is not None else None)
+    nets = [(d.get_model(Denoiser.MODEL, False), 0, tr.p)]
+    if sp0 is not None:
+        nets.append((d.get_model(Denoiser.SIGMA_ESTIMATOR, False), d._n_main, tr.ps))
     clean, noisy, ref, coords, npar = train_inputs(alg, style, ch)
     MD = NoisyDataset.Metadata
     meta = {MD.INPUT_NOISE_VALUES: npar, MD.CLEAN: clean}
     if alg == "n2v":
         meta[MD.MASK_COORDS] = coords
-    flat0 = d.flat.clone()
     for it in range(3):
         lr = R.trainer_lr((it + 1) * 40, 1000)
-        out = d.train_step([noisy, ref, meta], lr)
-        r = tr.step(lr, noisy, ref, npar, coords)
+        start = _flat_of(d, nets, tr)
+        d.flat.copy_(start)
+        d.adam_m.copy_(_cat_state(d, nets, tr, tr.m))
+        d.adam_v.copy_(_cat_state(d, nets, tr, tr.v))
+        d.adam_steps = tr.steps
+        d.mark_dirty()
+        out = d.run_pipeline([noisy, ref, meta])
+        d._last_engine.backward()
+        for t in tr.leaves:
+            t.grad = None
+        r = tr.forward(noisy, ref, npar, coords)
+        r["loss"].mean().backward()
         loss = out[PipelineOutput.LOSS].detach().cpu().numpy()
-        np.testing.assert_allclose(loss, g["loss_it%d" % it], rtol=1e-2, atol=2e-3, err_msg="loss at iteration %d vs reference" % it)
-        np.testing.assert_allclose(loss, r["loss"].detach().numpy(), rtol=1e-2, atol=2e-3)
+        np.testing.assert_allclose(loss, r["loss"].detach().numpy(), rtol=1e-2, atol=2e-3, err_msg="loss, iteration %d" % it)
+        np.testing.assert_allclose(loss, g["loss_it%d" % it], rtol=1e-2, atol=2e-3, err_msg="loss vs reference golden, iteration %d" % it)
         if it == 0:
             o = out[PipelineOutput.IMG_DENOISED].detach().cpu()
             # posterior mean vs the reference's: 1e-2 (with an ESTIMATED, still tiny sigma the PME weights amplify fp16 error)
             assert float((o - torch.from_numpy(g["out0"])).norm() / torch.from_numpy(g["out0"]).norm()) <= 1e-2
-    torch.cuda.synchronize()
-    # parameter updates: device vs oracle
-    upd = (d.flat - flat0).cpu()
-    nets = [(d.get_model(Denoiser.MODEL, False), 0, p0, tr.p)]
-    if sp0 is not None:
-        nets.append((d.get_model(Denoiser.SIGMA_ESTIMATOR, False), d._n_main, sp0, tr.ps))
-    for net, base, start, cur in nets:
-        du, ru = [], []
+        gd, gr = d.flat_grad.cpu(), _flat_grad_of(d, nets, tr)
+        cos = float((gd * gr).sum() / (gd.norm() * gr.norm() + 1e-30))
+        agree = float(((gd > 0) == (gr > 0)).float().mean())
+        assert cos >= 0.985 and agree >= 0.95, "iteration %d: gradient cosine %.4f, sign agreement %.4f" % (it, cos, agree)
+        d.optimizer_step(lr)
+        tr.steps += 1
+        with torch.no_grad():
+            for t, m, v in zip(tr.leaves, tr.m, tr.v):
+                R.adam_step(t, t.grad, m, v, tr.steps, lr)
+        torch.cuda.synchronize()
+        du, ru = d.flat.cpu() - start, _flat_of(d, nets, tr) - start
+        ucos = float((du * ru).sum() / (du.norm() * ru.norm() + 1e-30))
+        assert ucos >= 0.9, "iteration %d: Adam update cosine %.4f" % (it, ucos)
+        assert float(du.abs().max()) <= lr * 3.5       # |m_hat/sqrt(v_hat)| <= ~3.2 for betas (0.9, 0.99) in the first steps
+
+
+def _cat_state(d, net_list, tr, state):
+    """oracle Adam moment list (ordered like tr.leaves) -> flat layout"""
+    f = torch.zeros(d.flat.numel())
+    idx = {id(t): s for t, s in zip(tr.leaves, state)}
+    for net, base, cur in net_list:
         for l in net.layers:
-            for suffix, off, n in ((".weight", l.w_off, l.M * l.cin * l.k * l.k), (".bias", l.b_off, l.M)):
-                du.append(upd[base + off: base + off + n])
-                ru.append((cur[l.name + suffix].detach() - start[l.name + suffix]).reshape(-1))
-        du, ru = torch.cat(du), torch.cat(ru)
-        cos = float((du * ru).sum() / (du.norm() * ru.norm() + 1e-30))
-        assert cos >= 0.9, "update direction cosine %.4f" % cos
-        assert 0.8 <= float(du.norm() / ru.norm()) <= 1.25
-    if mode == "const" and alg == "ssdn":
-        est = float(d.l_params[Denoiser.ESTIMATED_SIGMA].detach().cpu().reshape(-1)[0])
-        assert est == pytest.approx(float(tr.est.detach().reshape(-1)[0]), abs=5e-5)
+            f[base + l.w_off: base + l.w_off + l.M * l.cin * l.k * l.k] = idx[id(cur[l.name + ".weight"])].reshape(-1)
+            f[base + l.b_off: base + l.b_off + l.M] = idx[id(cur[l.name + ".bias"])]
+    if tr.est is not None:
+        f[d._n_main + d._n_sig] = float(idx[id(tr.est)].reshape(-1)[0])
+    return f
 
 
 def test_reference_training_idiom_backward_bridge():
