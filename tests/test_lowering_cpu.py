@@ -53,14 +53,44 @@ def _check_lowering(cin, cout, bs, B, P):
         np.testing.assert_allclose(gb.numpy(), rb.numpy(), rtol=1e-8, atol=1e-10 * (float(rb.abs().max()) + 1e-12), err_msg=l.name)
 
 
+def _validate_with_library(op):
+    """ask libssdn_hip.so itself (no GPU needed) whether it accepts the planned tiling"""
+    import ctypes as C
+    from ssdn.hip import lib as L
+    a = op.a
+    fake = L.View(0x1000, 128, 0)
+    if op.type == "conv":
+        s = L.ConvArgs()
+        s.src0, s.src1 = fake, fake
+        s.c0, s.c1, s.up0, s.N, s.H, s.W, s.ntaps = a["c0"], a["c1"], a["up0"], a["N"], a["H"], a["W"], len(a["taps"])
+        for i, (dy, dx) in enumerate(a["taps"]):
+            s.dy[i], s.dx[i] = dy, dx
+        s.M, s.Mpad, s.Ktot, s.kc = a["M"], a["Mpad"], a["Ktot"], a["kc"]
+        s.ltw, s.lth, s.ltn, s.bf16 = a["ltw"], a["lth"], a["ltn"], a["bf16"]
+        s.dst32 = 0x1000 if a["dst32"] is not None else None
+        rc = L.load().ssdn_conv_lds_bytes(C.byref(s))
+    else:
+        s = L.WgradArgs()
+        s.dz, s.src0, s.src1 = fake, fake, fake
+        s.c0, s.c1, s.up0, s.N, s.H, s.W, s.ntaps = a["c0"], a["c1"], a["up0"], a["N"], a["H"], a["W"], len(a["taps"])
+        for i, (dy, dx) in enumerate(a["taps"]):
+            s.dy[i], s.dx[i], s.coff[i] = dy, dx, a["coff"][i]
+        s.M, s.Mpad, s.Ktot, s.Kpad, s.nslabs = a["M"], a["Mpad"], a["Ktot"], a["Kpad"], a["nslabs"]
+        s.ltw, s.lth, s.ltn = a["ltw"], a["lth"], a["ltn"]
+        rc = L.load().ssdn_wgrad_lds_bytes(C.byref(s))
+    assert 0 <= rc <= 160 * 1024, (op.type, a["layer"], rc, L.load().ssdn_last_error())
+
+
 def test_plan_tilings_fit_lds():
-    """every conv / wgrad tiling of the BASELINE configurations fits the 160 KiB LDS of a CU"""
+    """every conv / wgrad tiling of the BASELINE configurations is accepted by the library and fits the 160 KiB LDS of a CU"""
     from ssdn.hip.graph import LDS_LIMIT
     for (cin, cout, bs, B, P) in [(3, 9, True, 32, 64), (3, 9, True, 16, 128), (3, 3, False, 32, 64), (1, 1, False, 4, 32),
                                   (3, 9, True, 2, 768), (3, 9, True, 2, 512)]:
         plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=256, train=P <= 128)
         for op in plan.fwd + plan.bwd:
             a = op.a
+            if op.type in ("conv", "wgrad"):
+                _validate_with_library(op)
             if op.type == "conv":
                 padT = max(0, -min(t[0] for t in a["taps"])); padB = max(0, max(t[0] for t in a["taps"]))
                 padL = max(0, -min(t[1] for t in a["taps"])); padR = max(0, max(t[1] for t in a["taps"]))
