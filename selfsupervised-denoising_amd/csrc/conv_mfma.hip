@@ -45,8 +45,9 @@ static __host__ __device__ inline ConvGeom conv_geom(int ltw, int lth, int ltn, 
     return g;
 }
 
-static __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned magic) { return __umulhi(x, magic); }
-static inline unsigned magic_of(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+// exact x / d for x*d < 2^32 via a 32-bit magic reciprocal; magic == 0 encodes d == 1 (its reciprocal does not fit)
+static __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
+static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 
 struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
@@ -176,15 +177,30 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         const char* b0p = tile + bbase[0] + toff;
         const char* b1p = tile + bbase[1] + toff;
         const char* ap = wl + abase;
-        for (int s = 0; s < a.kc; s += 16) {
-            half8 b0 = *reinterpret_cast<const half8*>(b0p + s * 2);
-            half8 b1 = *reinterpret_cast<const half8*>(b1p + s * 2);
+        // software-pipelined K loop: the fragments of K-step s+1 are fetched from LDS while the 2*MT MFMAs of K-step s run
+        half8 bc0 = *reinterpret_cast<const half8*>(b0p);
+        half8 bc1 = *reinterpret_cast<const half8*>(b1p);
+        half8 ac[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ac[mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR);
+        for (int s = 16; s <= a.kc; s += 16) {
+            half8 bn0 = bc0, bn1 = bc1, an[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) an[mt] = ac[mt];
+            if (s < a.kc) {
+                bn0 = *reinterpret_cast<const half8*>(b0p + s * 2);
+                bn1 = *reinterpret_cast<const half8*>(b1p + s * 2);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) an[mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR + s * 2);
+            }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                half8 av = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR + s * 2);
-                acc[mt][0] = mma<BF>(av, b0, acc[mt][0]);
-                acc[mt][1] = mma<BF>(av, b1, acc[mt][1]);
+                acc[mt][0] = mma<BF>(ac[mt], bc0, acc[mt][0]);
+                acc[mt][1] = mma<BF>(ac[mt], bc1, acc[mt][1]);
             }
+            bc0 = bn0; bc1 = bn1;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) ac[mt] = an[mt];
         }
     };
     // after the MFMA work of `step`: make step+1 runnable (re-stage the tile if it starts a new channel chunk, move its

@@ -61,8 +61,8 @@ static __host__ __device__ inline WgGeom wg_geom(const ssdn_wgrad_args& a) {
     return g;
 }
 
-static __device__ __forceinline__ unsigned fdivw(unsigned x, unsigned magic) { return __umulhi(x, magic); }
-static inline unsigned magic_ofw(unsigned d) { return (unsigned)((0x100000000ull + d - 1) / d); }
+static __device__ __forceinline__ unsigned fdivw(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
+static inline unsigned magic_ofw(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 
 struct WgAux {
     unsigned mg_hw, mg_hh;

@@ -118,7 +118,8 @@ def _out_of(op):
     return None
 
 
-CASES = [(3, 9, True, 2, 32), (1, 2, True, 1, 32), (3, 3, False, 2, 32), (3, 9, True, 1, 64), (3, 1, False, 2, 64)]
+# the (3, 9, True, 8, 32) case makes the planner pick multi-image tiles with one-row halos (TH = 1, TN > 1) for the 1x1 head
+CASES = [(3, 9, True, 2, 32), (1, 2, True, 1, 32), (3, 3, False, 2, 32), (3, 9, True, 1, 64), (3, 1, False, 2, 64), (3, 9, True, 8, 32)]
 
 
 @pytest.mark.parametrize("cin,cout,bs,B,P", CASES)
