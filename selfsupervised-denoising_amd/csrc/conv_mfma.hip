@@ -15,6 +15,7 @@
 //   and committed to the idle buffer afterwards -- one barrier per step, L2 latency of the weight stream hidden.
 //   pixel / weight row stride = 16 B x odd  =>  ds_read_b128 of 16 different pixels hits 16 different 16-B bank slots.
 #include "common.h"
+#include <cstdlib>
 
 #define CONV_THREADS 256
 
@@ -48,6 +49,7 @@ static __host__ __device__ inline ConvGeom conv_geom(int ltw, int lth, int ltn, 
 // exact x / d for x*d < 2^32 via a 32-bit magic reciprocal; magic == 0 encodes d == 1 (its reciprocal does not fit)
 static __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
 static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
+static __device__ __forceinline__ unsigned magic_dev(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 
 struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
@@ -56,6 +58,7 @@ struct ConvAux {  // host-computed helpers passed by value
     int lg;                 // log2(threads cooperating on one pixel when staging the tile)
     int cc8;                // 16-B chunks per pixel per channel chunk (= kc/8)
     int m_base;             // first output channel of this launch (multiple of 32)
+    int ablate;             // tuning aid (env SSDN_CONV_ABLATE): 1 no MFMA, 2 no tile staging, 4 no weight stream, 8 no stores
 };
 
 #define CONV_NW 3  // 16-B registers per thread per prefetched weight slice: MT*32 rows x kc channels <= 3*256*8 halves (MT=3: kc<=64)
@@ -129,6 +132,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     }
     half8 wrA[CONV_NW], wrB[CONV_NW];   // two register sets: the weight stream runs TWO steps ahead of the MFMA work
     auto w_issue = [&](half8 (&wr)[CONV_NW], int step) {
+        if (x.ablate & 4) return;
         const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
         const h16* base = wp + (long long)t * a.Mpad * a.Ktot + ch * a.kc;
 #pragma unroll
@@ -136,11 +140,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             if (w_goff[i] >= 0) wr[i] = ld_h8(base + w_goff[i]);
     };
     auto w_commit = [&](half8 (&wr)[CONV_NW], char* buf) {
+        if (x.ablate & 4) return;
 #pragma unroll
         for (int i = 0; i < CONV_NW; ++i)
             if (w_goff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wr[i];
     };
     auto stage_tile = [&](int ch) {
+        if (x.ablate & 2) return;
         if (sub < x.cc8) {
             const int k = ch * a.kc + sub * 8;
             const bool from0 = k < a.c0;
@@ -171,6 +177,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         }
     };
     auto compute = [&](const char* wl, int step) {
+        if (x.ablate & 1) return;
         const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
         (void)ch;
         const int toff = (a.dy[t] * g.HW + a.dx[t]) * g.PSTR;
@@ -237,17 +244,42 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     }
 
     // ---- epilogue: D row = 8*(r>>2) + 4*(lane>>5) + (r&3)  (output channel), D col = lane&31 (pixel) -------------
+    if (a.dst32) {
+        // fp32 NCHW planar output (net_out of the last 1x1 layer: M <= 9 channels): direct stores, coalesced along x
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int n = pn[nt], y = py[nt], xx = px[nt];
+            if (n >= a.N || y >= a.H || xx >= a.W || (x.ablate & 8)) continue;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = x.m_base + mt * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
+                    if (m >= a.M) continue;
+                    float v = acc[mt][nt][r];
+                    if (a.bias) v += a.bias[m];
+                    if (a.act) v = lrelu(v);
+                    a.dst32[(((long long)n * a.M + m) * a.H + y) * a.W + xx] = v;
+                }
+        }
+        return;
+    }
+    // 16-bit NHWC output: the tile is transposed through LDS (the input tile is dead after the last barrier) so that HBM
+    // sees whole 16-byte-per-lane, pixel-contiguous stores instead of 8-byte fragments of every cache line
+    // (measured on the 96-channel full-resolution layers: 60-75 us of a 190 us launch were the fragmented stores).
+    const int OSTR = MT * 64 + 16;
+    char* ot = smem;
+    const int npix = g.TN * g.TH * g.TW;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
-        const int n = pn[nt], y = py[nt], xx = px[nt];
-        if (n >= a.N || y >= a.H || xx >= a.W) continue;
-        const long long pix = ((long long)n * a.H + y) * a.W + xx;
+        const int q = wave * 64 + nt * 32 + l31;
+        if (q >= npix) continue;      // tile smaller than 256 pixels: surplus lanes have nothing to write
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
-                const int m = x.m_base + mt * 32 + gq * 8 + kh * 4;
-                if (m >= a.M) continue;
+                const int ml = mt * 32 + gq * 8 + kh * 4;
+                const int m = x.m_base + ml;
                 float v[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -255,39 +287,75 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
                     if (a.bias && m + j < a.M) v[j] += a.bias[m + j];
                     if (a.act) v[j] = lrelu(v[j]);
                 }
-                if (a.dst32) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (m + j < a.M) a.dst32[(((long long)n * a.M + m + j) * a.H + y) * a.W + xx] = v[j];
-                    continue;
-                }
-                if (a.add.p) {
-                    if constexpr (BF) {
-                        u16x4 ad = ld_b4((const unsigned short*)a.add.p + pix * a.add.cs + a.add.co + m);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += bf2f(ad[j]);
-                    } else {
-                        half4 ad = ld_h4((const h16*)a.add.p + pix * a.add.cs + a.add.co + m);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] += (float)ad[j];
-                    }
-                }
-                if (a.mask.p) {
-                    half4 mk = ld_h4((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) v[j] *= lrelu_grad((float)mk[j]);
-                }
                 if constexpr (BF) {
                     u16x4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-                    st_b4((unsigned short*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+                    *reinterpret_cast<u16x4*>(ot + q * OSTR + ml * 2) = o;
                 } else {
                     half4 o;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) o[j] = (h16)v[j];
-                    st_h4((h16*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+                    *reinterpret_cast<half4*>(ot + q * OSTR + ml * 2) = o;
                 }
+            }
+        }
+    }
+    __syncthreads();
+    if (x.ablate & 8) return;
+    int m_cnt = a.M - x.m_base;
+    m_cnt = m_cnt > MT * 32 ? MT * 32 : m_cnt;
+    const int cpp = m_cnt >> 3;                       // 16-byte chunks per pixel
+    {
+        const unsigned mg = magic_dev(cpp);
+        for (int e = tid; e < npix * cpp; e += CONV_THREADS) {
+            const int q = mg ? __umulhi((unsigned)e, mg) : e;
+            const int c = e - q * cpp;
+            const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
+            const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
+            if (n >= a.N || y >= a.H || xx >= a.W) continue;
+            const long long pix = ((long long)n * a.H + y) * a.W + xx;
+            const int m = x.m_base + c * 8;
+            if constexpr (BF) {
+                u16x8 o = *reinterpret_cast<const u16x8*>(ot + q * OSTR + c * 16);
+                if (a.add.p || a.mask.p) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = bf2f(o[j]);
+                    if (a.add.p) {
+                        u16x8 ad = ld_b8((const unsigned short*)a.add.p + pix * a.add.cs + a.add.co + m);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += bf2f(ad[j]);
+                    }
+                    if (a.mask.p) {
+                        half8 mk = ld_h8((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad((float)mk[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
+                }
+                st_b8((unsigned short*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+            } else {
+                half8 o = *reinterpret_cast<const half8*>(ot + q * OSTR + c * 16);
+                if (a.add.p || a.mask.p) {
+                    float v[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = (float)o[j];
+                    if (a.add.p) {
+                        half8 ad = ld_h8((const h16*)a.add.p + pix * a.add.cs + a.add.co + m);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] += (float)ad[j];
+                    }
+                    if (a.mask.p) {
+                        half8 mk = ld_h8((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad((float)mk[j]);
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
+                }
+                st_h8((h16*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
             }
         }
     }
@@ -306,7 +374,9 @@ static int conv_validate(const ssdn_conv_args* a) {
             return ssdn_set_error("conv: weight slice %d x %d exceeds the prefetch registers (kc*MT <= %d)", mt * 32, a->kc, CONV_NW * CONV_THREADS / 4);
     }
     if ((a->Mpad & 31) || a->M > a->Mpad) return ssdn_set_error("conv: Mpad must be a multiple of 32 and >= M");
-    if (!a->dst32 && (a->M & 3)) return ssdn_set_error("conv: fp16 output needs M %% 4 == 0");
+    if (!a->dst32 && ((a->M & 7) || (a->dst.co & 7) || (a->dst.cs & 7))) return ssdn_set_error("conv: 16-bit output needs M, dst.co, dst.cs %% 8 == 0");
+    if (a->add.p && ((a->add.co & 7) || (a->add.cs & 7))) return ssdn_set_error("conv: add view must be 16-byte aligned");
+    if (a->mask.p && ((a->mask.co & 7) || (a->mask.cs & 7))) return ssdn_set_error("conv: mask view must be 16-byte aligned");
     if (a->up0 && ((a->H | a->W) & 1)) return ssdn_set_error("conv: upsampled source needs even H, W");
     if (a->c1 > 0 && !a->src1.p) return ssdn_set_error("conv: src1 missing");
     if (a->bf16 && a->dst32) return ssdn_set_error("conv: fp32 output is only implemented for the fp16 (forward) role");
@@ -318,12 +388,16 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     int mt = a->Mpad / 32;
     if (mt > 3) mt = 3;
-    return g.NP * g.PSTR + 2 * mt * 32 * g.WSTR;
+    int main_b = g.NP * g.PSTR + 2 * mt * 32 * g.WSTR;
+    int epi_b = a->dst32 ? 0 : (g.TN * g.TH * g.TW) * (mt * 64 + 16);
+    return main_b > epi_b ? main_b : epi_b;
 }
 
 template <int MT, bool BF>
 static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
     size_t lds = (size_t)g.NP * g.PSTR + 2 * (size_t)MT * 32 * g.WSTR;
+    size_t epi = a->dst32 ? 0 : (size_t)(g.TN * g.TH * g.TW) * (MT * 64 + 16);
+    lds = lds > epi ? lds : epi;
     if (lds > 160 * 1024) return ssdn_set_error("conv: tiling needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
@@ -361,6 +435,10 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     while ((1 << x.lg) < x.cc8) ++x.lg;
     if (x.lg > 8) return ssdn_set_error("conv: kc too large");
     x.m_base = 0;
+    {
+        const char* e = getenv("SSDN_CONV_ABLATE");
+        x.ablate = e ? atoi(e) : 0;
+    }
     // output channels in launches of 96 (MT=3); the tail uses MT = 1 or 2
     int full = a->Mpad / 96, rem = (a->Mpad % 96) / 32;
     const bool bf = a->bf16 != 0;

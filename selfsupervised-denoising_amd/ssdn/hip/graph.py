@@ -137,7 +137,7 @@ def _pow2ceil_log(v: int) -> int:
     return l
 
 
-def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT):
+def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
     """Pick (ltw, lth, ltn, kc) for SSDN_OP_CONV: <= 256 pixels per workgroup, LDS = halo tile + two weight slices."""
     padT, padB, padL, padR = _pads(taps)
     mt = min(3, Mpad // 32)
@@ -153,6 +153,8 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT):
                 NP = TN * (TH + padT + padB) * (TW + padL + padR)
                 for kc in kcs:
                     lds = NP * (kc * 2 + 16) + 2 * mt * 32 * (kc * 2 + 16)
+                    if out16:      # the output tile is transposed through the same LDS in the epilogue
+                        lds = max(lds, TN * TH * TW * (mt * 64 + 16))
                     if lds > budget:
                         continue
                     halo = NP / float(TN * TH * TW)
@@ -240,7 +242,7 @@ class NetPlan:
               bias=True, act=True, mask=None, add=None):
         Ktot = c0 + c1
         Mpad = ceil_to(M, 32)
-        ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad)
+        ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None)
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                    taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
                                    dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"))))
