@@ -3,6 +3,7 @@
 #include "common.h"
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 
 static thread_local char g_err[512] = "";
 
@@ -118,12 +119,41 @@ int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* f
 int ssdn_conv_lds_bytes(const ssdn_conv_args* a) { return conv_lds_bytes(a); }
 int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a) { return wgrad_lds_bytes(a); }
 
+#define SSDN_NEVENTS 64
+static hipStream_t g_side = nullptr;
+static hipEvent_t g_ev[SSDN_NEVENTS];
+static int g_ev_next = 0;
+static bool g_lanes_ready = false;
+static int lanes_init() {
+    if (g_lanes_ready) return 0;
+    SSDN_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    for (int i = 0; i < SSDN_NEVENTS; ++i) SSDN_CHECK_HIP(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
+    g_lanes_ready = true;
+    return 0;
+}
+
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
-    hipStream_t s = (hipStream_t)stream;
+    hipStream_t main_s = (hipStream_t)stream;
+    bool main_dirty = true, side_used = false;   // main_dirty: lane 0 has work the side stream has not been ordered after
+    static const bool one_lane = getenv("SSDN_ONE_LANE") != nullptr;   // tuning / debugging aid
     for (int i = 0; i < n; ++i) {
         const void* p = ops[i].args;
         int rc = 0;
         if (!p) return ssdn_set_error("op %d: null args", i);
+        hipStream_t s = main_s;
+        if (ops[i].lane == 1 && !one_lane) {
+            if (lanes_init()) return -1;
+            if (main_dirty) {
+                hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
+                SSDN_CHECK_HIP(hipEventRecord(e, main_s));
+                SSDN_CHECK_HIP(hipStreamWaitEvent(g_side, e, 0));
+                main_dirty = false;
+            }
+            s = g_side;
+            side_used = true;
+        } else {
+            main_dirty = true;
+        }
         switch (ops[i].type) {
             case SSDN_OP_PACK_INPUT: rc = launch_pack_input((const ssdn_pack_input_args*)p, s); break;
             case SSDN_OP_CONV: rc = launch_conv((const ssdn_conv_args*)p, s); break;
@@ -159,6 +189,11 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             snprintf(tmp, sizeof(tmp), "%s", g_err);
             return ssdn_set_error("op %d (type %d): %s", i, ops[i].type, tmp);
         }
+    }
+    if (side_used) {   // join
+        hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
+        SSDN_CHECK_HIP(hipEventRecord(e, g_side));
+        SSDN_CHECK_HIP(hipStreamWaitEvent(main_s, e, 0));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ssdn_set_error("launch error: %s", hipGetErrorString(e));

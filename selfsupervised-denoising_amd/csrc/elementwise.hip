@@ -362,9 +362,19 @@ __global__ void k_wreduce(ssdn_wreduce_args a, int step) {
             a.gw[o] = acc * inv;
         }
     } else if (idx < stride + a.M && a.gb) {
+        // bias gradient: 16 independent loads in flight per round (a dependent one-at-a-time loop over 256 slabs is
+        // pure L2 latency: it alone cost 30-60 us per layer), summed in slab order
         int m = idx - stride;
         float acc = 0.f;
-        for (int s = 0; s < a.nslabs; ++s) acc += a.bslab[(long long)s * a.Mpad + m];
+        int s = 0;
+        for (; s + 16 <= a.nslabs; s += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = a.bslab[(long long)(s + u) * a.Mpad + m];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) acc += v[u];
+        }
+        for (; s < a.nslabs; ++s) acc += a.bslab[(long long)s * a.Mpad + m];
         a.gb[a.m_off + m] = acc * inv;
     }
 }

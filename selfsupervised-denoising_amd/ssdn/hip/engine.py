@@ -21,11 +21,15 @@ def _ptr(t: torch.Tensor, byte_off: int = 0) -> int:
 class OpList:
     """A materialised op list: a ctypes array of ssdn_op plus the argument structs it points to."""
 
-    def __init__(self, recs):
-        self.args = [a for _, a in recs]                      # keep the structs alive
+    SIDE_LANE = ("wgrad", "wreduce")     # weight-gradient GEMMs + slab reductions run on the library's side stream
+
+    def __init__(self, recs, lanes: bool = False):
+        self.args = [r[1] for r in recs]                      # keep the structs alive
         self.arr = (L.OpRec * max(1, len(recs)))()
-        for i, (ty, a) in enumerate(recs):
+        for i, r in enumerate(recs):
+            ty, a = r[0], r[1]
             self.arr[i].type = L.OP[ty]
+            self.arr[i].lane = 1 if (lanes and ty in self.SIDE_LANE) else 0
             self.arr[i].args = C.cast(C.pointer(a), C.c_void_p)
         self.n = len(recs)
 
@@ -55,7 +59,7 @@ class DeviceNet:
             # zero-initialised once: padding channels / never-written slab corners must be finite
             self.t[name] = torch.zeros(spec.shape, dtype=self.DT[spec.kind], device=device)
         self.fwd = OpList([self._mat(op) for op in plan.fwd])
-        self.bwd = OpList([self._mat(op) for op in plan.bwd])
+        self.bwd = OpList([self._mat(op) for op in plan.bwd], lanes=True)
         self.pack = OpList([self._mat(op) for op in plan.pack])
 
     # ---- helpers ------------------------------------------------------------------------------------------

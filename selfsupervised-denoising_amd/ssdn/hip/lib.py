@@ -25,7 +25,7 @@ class View(C.Structure):
 
 
 class OpRec(C.Structure):
-    _fields_ = [("type", i32), ("_pad", i32), ("args", vp)]
+    _fields_ = [("type", i32), ("lane", i32), ("args", vp)]
 
 
 class PackInputArgs(C.Structure):
