@@ -71,6 +71,7 @@ class NoiseNetwork(nn.Module):
         self.output_block = _Slots(blocks["output_block"])
         self._engines: Dict[Tuple[int, int, int], list] = {}   # shape -> [DeviceNet, parameter version its shadows hold]
         self._version = 0
+        self._consume_default_init_draws()
         self.init_weights()
 
     # ---- reference surface ----------------------------------------------------------------------------------
@@ -82,6 +83,18 @@ class NoiseNetwork(nn.Module):
     def input_wh_mul() -> int:
         """Inputs must be multiples of 2^5 in both dimensions (five pooling levels, noise_network.py:228-238)."""
         return 32
+
+    def _consume_default_init_draws(self):
+        """The reference builds nn.Conv2d modules, whose constructors draw a default (uniform) initialisation for every
+        weight and bias from the global generator BEFORE init_weights() overwrites them (noise_network.py:69-159).  Those
+        numbers are never used, but they advance the generator; drawing the same amounts in the same construction order keeps
+        `torch.manual_seed(s); NoiseNetwork(...)` bit-identical to the reference (tests/test_dropin_surface.py)."""
+        by_name = {l.name: l for l in self.layers}
+        order = [l for l in self.layers if not l.name.startswith("output_block")]
+        order += [by_name["output_block.4"], by_name["output_block.0"], by_name["output_block.2"]]   # output_conv is built first
+        for l in order:
+            torch.empty(l.M, l.cin, l.k, l.k).uniform_(-1, 1)
+            torch.empty(l.M).uniform_(-1, 1)
 
     def init_weights(self):
         """He-normal for LeakyReLU(0.1) on every conv, zero biases; last layer 'linear' gain or zeros
