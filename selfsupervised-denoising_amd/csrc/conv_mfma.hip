@@ -1,4 +1,4 @@
-// conv_mfma.hip -- im2col-free implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x16_f16).
+// conv_mfma.hip -- im2col-free implicit-GEMM convolution on the CDNA4 matrix cores (v_mfma_f32_32x32x16_{f16,bf16}).
 //
 // One kernel serves every 3x3 / 1x1 convolution of the U-Net in both roles:
 //   forward       out = lrelu(bias + sum_t W_t * in(y+dy_t, x+dx_t))          (ShiftConv2d / Conv2d, noise_network.py:58-156,241-260)
@@ -7,13 +7,17 @@
 // two-source tile loader; nothing is padded, cropped, upsampled or concatenated in HBM.
 //
 // GEMM view per workgroup: D[m][pixel] += A[m][k] * B[k][pixel];  A = packed weights (rows = output channels),
-// B = the input halo tile staged ONCE in LDS as NHWC fp16 (every tap is a different LDS offset of the same tile).
+// B = the input halo tile staged ONCE per channel chunk in LDS as NHWC (every tap is a different LDS offset of the same tile).
 //   workgroup = 256 threads = 4 waves; tile = up to 256 output pixels (2^ltn images x 2^lth rows x 2^ltw cols)
 //   wave w owns pixels [64w, 64w+64) = two 32-wide MFMA column tiles, and all MT (<=3) 32-row output-channel tiles
-//   LDS: halo tile [TN][TH+padT+padB][TW+padL+padR] pixels x (kc fp16 + 16 B pad)  +  TWO weight slices [32*MT][kc] (+pad):
-//   the slice of step s+1 (next tap / channel chunk) is prefetched global->registers while step s runs on the MFMA pipe
-//   and committed to the idle buffer afterwards -- one barrier per step, L2 latency of the weight stream hidden.
-//   pixel / weight row stride = 16 B x odd  =>  ds_read_b128 of 16 different pixels hits 16 different 16-B bank slots.
+//   LDS: halo tile [TN][TH+padT+padB][TW+padL+padR] pixels x (KC fp16 + 16 B pad)  +  TWO weight slices [32*MT][KC] (+pad).
+//   Pixel / weight-row stride = 16 B x odd  =>  ds_read_b128 of 16 different pixels hits 16 different 16-B bank slots.
+// Software pipeline over (channel chunk, tap) steps: the weight slices of steps s+1 and s+2 are in flight global->registers
+// while step s runs on the matrix cores; a slice is committed to the idle LDS buffer one step before its use; one barrier
+// per step.  Inside a step the KS = KC/16 K-steps are fully unrolled with ping-pong fragment registers and immediate LDS
+// offsets (KC is a template parameter): PMC showed the first version issuing 12 VALU per MFMA -- register moves and address
+// arithmetic -- which is what this structure removes.
+// Epilogue: bias (+LeakyReLU) in registers, tile transposed through LDS, 16-byte pixel-contiguous stores.
 #include "common.h"
 #include <cstdlib>
 
@@ -53,15 +57,10 @@ static __device__ __forceinline__ unsigned magic_dev(unsigned d) { return d <= 1
 
 struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
-    unsigned mg_cc8;        // magic reciprocal of cc8
     unsigned mg_ntaps;      // magic reciprocal of ntaps
-    int lg;                 // log2(threads cooperating on one pixel when staging the tile)
-    int cc8;                // 16-B chunks per pixel per channel chunk (= kc/8)
     int m_base;             // first output channel of this launch (multiple of 32)
     int ablate;             // tuning aid (env SSDN_CONV_ABLATE): 1 no MFMA, 2 no tile staging, 4 no weight stream, 8 no stores
 };
-
-#define CONV_NW 3  // 16-B registers per thread per prefetched weight slice: MT*32 rows x kc channels <= 3*256*8 halves (MT=3: kc<=64)
 
 template <bool BF>
 static __device__ __forceinline__ f32x16 mma(half8 av, half8 bv, f32x16 c) {
@@ -73,35 +72,39 @@ static __device__ __forceinline__ f32x16 mma(half8 av, half8 bv, f32x16 c) {
 
 // BF = false: fp16 operands / fp16 output (forward);  BF = true: bf16 operands / bf16 output (data gradient).
 // Tiles are moved through LDS as raw 16-bit words, so only the MFMA opcode and the epilogue conversions differ.
-template <int MT, bool BF>
+// KS = channel chunk / 16 (K-steps per pipeline step).
+template <int MT, bool BF, int KS>
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, ConvAux x) {
+    constexpr int KC = KS * 16;            // channels per chunk
+    constexpr int CC8 = KS * 2;            // 16-byte pieces per pixel / weight row
+    constexpr int STR = KC * 2 + 16;       // LDS stride of a pixel and of a weight row (bytes)
+    constexpr int WROWS = MT * 32;
+    constexpr int NW = (WROWS * CC8 + CONV_THREADS - 1) / CONV_THREADS;   // 16-B registers per thread per weight slice
+    constexpr int WBUF = WROWS * STR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, a.kc);
+    const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, KC);
     char* tile = smem;
-    char* wl0 = smem + (size_t)g.NP * g.PSTR;           // two weight-slice buffers (double buffering)
-    const int wbuf_bytes = MT * 32 * g.WSTR;
+    char* wl0 = smem + (size_t)g.NP * STR;
+    char* wl1 = wl0 + WBUF;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l31 = lane & 31, kh = lane >> 5;
-    // tile origin
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int bid = blockIdx.x;
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
     const int n0 = bid * g.TN, y0 = ty_i * g.TH, x0 = tx_i * g.TW;
+    const int npix = g.TN * g.TH * g.TW;
 
     // this lane's two output pixels (MFMA columns)
-    int bbase[2], pn[2], py[2], px[2];
+    int bbase[2];
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         int q = wave * 64 + nt * 32 + l31;
         int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
-        pn[nt] = n0 + tn; py[nt] = y0 + ty; px[nt] = x0 + tx;
-        if (tn >= g.TN) {  // tile smaller than 256 pixels: surplus lanes compute on pixel 0 and store nothing
-            pn[nt] = a.N;
-            tn = ty = tx = 0;
-        }
-        bbase[nt] = ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * g.PSTR + kh * 16;
+        if (tn >= g.TN) tn = ty = tx = 0;   // tile smaller than 256 pixels: surplus lanes compute on pixel 0, store nothing
+        bbase[nt] = ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * STR + kh * 16;
     }
-    const int abase = l31 * g.WSTR + kh * 16;
+    const int abase = l31 * STR + kh * 16;
 
     f32x16 acc[MT][2];
 #pragma unroll
@@ -111,109 +114,105 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
-    const int G = 1 << x.lg, sub = tid & (G - 1), grp = tid >> x.lg, ngrp = CONV_THREADS >> x.lg;
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
-    const int nchunks = a.Ktot / a.kc;
+    const int nchunks = a.Ktot / KC;
+    const int nsteps = nchunks * a.ntaps;
     const h16* s0 = (const h16*)a.src0.p;
     const h16* s1 = (const h16*)a.src1.p;
     const h16* wp = (const h16*)a.w;
 
-    const int nsteps_ = nchunks * a.ntaps;
-    // weight-slice prefetch: element e = tid + 256*i  ->  row e / cc8, 16-B chunk e % cc8
-    const int wtotal = MT * 32 * x.cc8;
-    int w_goff[CONV_NW], w_loff[CONV_NW];
+    // ---- weight-slice prefetch: element e = tid + 256*i  ->  row e / CC8, 16-B piece e % CC8 (compile-time divisions) ----
+    int w_goff[NW], w_loff[NW];
 #pragma unroll
-    for (int i = 0; i < CONV_NW; ++i) {
-        int e = tid + i * CONV_THREADS;
-        int m = fdiv(e, x.mg_cc8);
-        int cc = e - m * x.cc8;
-        w_goff[i] = e < wtotal ? ((x.m_base + m) * a.Ktot + cc * 8) : -1;
-        w_loff[i] = m * g.WSTR + cc * 16;
+    for (int i = 0; i < NW; ++i) {
+        const int e = tid + i * CONV_THREADS;
+        const int m = e / CC8, cc = e % CC8;
+        w_goff[i] = e < WROWS * CC8 ? ((x.m_base + m) * a.Ktot + cc * 8) : -1;
+        w_loff[i] = m * STR + cc * 16;
     }
-    half8 wrA[CONV_NW], wrB[CONV_NW];   // two register sets: the weight stream runs TWO steps ahead of the MFMA work
-    auto w_issue = [&](half8 (&wr)[CONV_NW], int step) {
+    half8 wrA[NW], wrB[NW];
+    auto w_issue = [&](half8 (&wr)[NW], int step) {
         if (x.ablate & 4) return;
         const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
-        const h16* base = wp + (long long)t * a.Mpad * a.Ktot + ch * a.kc;
+        const h16* base = wp + (long long)t * a.Mpad * a.Ktot + ch * KC;
 #pragma unroll
-        for (int i = 0; i < CONV_NW; ++i)
+        for (int i = 0; i < NW; ++i)
             if (w_goff[i] >= 0) wr[i] = ld_h8(base + w_goff[i]);
     };
-    auto w_commit = [&](half8 (&wr)[CONV_NW], char* buf) {
+    auto w_commit = [&](half8 (&wr)[NW], char* buf) {
         if (x.ablate & 4) return;
 #pragma unroll
-        for (int i = 0; i < CONV_NW; ++i)
+        for (int i = 0; i < NW; ++i)
             if (w_goff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wr[i];
     };
+
+    // ---- halo tile staging: flat index f = tid + 256*j over (halo pixel, 16-B piece); 4 loads in flight per thread ----
+    const int nflat = g.NP * CC8;
     auto stage_tile = [&](int ch) {
         if (x.ablate & 2) return;
-        if (sub < x.cc8) {
-            const int k = ch * a.kc + sub * 8;
-            const bool from0 = k < a.c0;
-            const h16* sp = from0 ? s0 + a.src0.co + k : s1 + a.src1.co + (k - a.c0);
-            const int scs = from0 ? a.src0.cs : a.src1.cs;
-            const int sh = from0 && a.up0 ? 1 : 0;
-            const int Hs = from0 ? H0 : a.H, Ws = from0 ? W0 : a.W;
-            for (int hp0 = grp; hp0 < g.NP; hp0 += 4 * ngrp) {
-                half8 v[4];
+        for (int f0 = tid; f0 < nflat; f0 += 4 * CONV_THREADS) {
+            half8 v[4];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int hp = hp0 + u * ngrp;
-                    unsigned r1 = fdiv(hp, x.mg_hw);
-                    int hx = hp - r1 * g.HW;
-                    unsigned tn = fdiv(r1, x.mg_hh);
-                    int hy = r1 - tn * g.HH;
-                    int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
-                    v[u] = zero_h8();
-                    if (hp < g.NP && n < a.N && y >= 0 && y < a.H && xx >= 0 && xx < a.W)
-                        v[u] = ld_h8(sp + (((long long)n * Hs + (y >> sh)) * Ws + (xx >> sh)) * scs);
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * CONV_THREADS;
+                const int hp = f / CC8, cc = f % CC8;
+                const unsigned r1 = fdiv(hp, x.mg_hw);
+                const int hx = hp - r1 * g.HW;
+                const unsigned tn = fdiv(r1, x.mg_hh);
+                const int hy = r1 - tn * g.HH;
+                const int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
+                const int k = ch * KC + cc * 8;
+                v[u] = zero_h8();
+                if (f < nflat && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
+                    if (k < a.c0) {
+                        const int sh = a.up0;
+                        v[u] = ld_h8(s0 + (long long)(((n * H0 + (y >> sh)) * W0 + (xx >> sh)) * a.src0.cs + a.src0.co + k));
+                    } else {
+                        v[u] = ld_h8(s1 + (long long)(((n * a.H + y) * a.W + xx) * a.src1.cs + a.src1.co + (k - a.c0)));
+                    }
                 }
+            }
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    int hp = hp0 + u * ngrp;
-                    if (hp < g.NP) *reinterpret_cast<half8*>(tile + (size_t)hp * g.PSTR + sub * 16) = v[u];
-                }
+            for (int u = 0; u < 4; ++u) {
+                const int f = f0 + u * CONV_THREADS;
+                if (f < nflat) *reinterpret_cast<half8*>(tile + (f / CC8) * STR + (f % CC8) * 16) = v[u];
             }
         }
     };
+
+    // ---- one pipeline step on the matrix cores: KS K-steps, fully unrolled, ping-pong fragments, immediate offsets ----
     auto compute = [&](const char* wl, int step) {
         if (x.ablate & 1) return;
         const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
-        (void)ch;
-        const int toff = (a.dy[t] * g.HW + a.dx[t]) * g.PSTR;
+        const int toff = (a.dy[t] * g.HW + a.dx[t]) * STR;
         const char* b0p = tile + bbase[0] + toff;
         const char* b1p = tile + bbase[1] + toff;
         const char* ap = wl + abase;
-        // software-pipelined K loop: the fragments of K-step s+1 are fetched from LDS while the 2*MT MFMAs of K-step s run
-        half8 bc0 = *reinterpret_cast<const half8*>(b0p);
-        half8 bc1 = *reinterpret_cast<const half8*>(b1p);
-        half8 ac[MT];
+        half8 bq[2][2], aq[2][MT];
+        bq[0][0] = *reinterpret_cast<const half8*>(b0p);
+        bq[0][1] = *reinterpret_cast<const half8*>(b1p);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ac[mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR);
-        for (int s = 16; s <= a.kc; s += 16) {
-            half8 bn0 = bc0, bn1 = bc1, an[MT];
+        for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * STR);
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) an[mt] = ac[mt];
-            if (s < a.kc) {
-                bn0 = *reinterpret_cast<const half8*>(b0p + s * 2);
-                bn1 = *reinterpret_cast<const half8*>(b1p + s * 2);
+        for (int ks = 0; ks < KS; ++ks) {
+            const int cur = ks & 1, nxt = cur ^ 1;
+            if (ks + 1 < KS) {
+                bq[nxt][0] = *reinterpret_cast<const half8*>(b0p + (ks + 1) * 32);
+                bq[nxt][1] = *reinterpret_cast<const half8*>(b1p + (ks + 1) * 32);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) an[mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * g.WSTR + s * 2);
+                for (int mt = 0; mt < MT; ++mt) aq[nxt][mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * STR + (ks + 1) * 32);
             }
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
-                acc[mt][0] = mma<BF>(ac[mt], bc0, acc[mt][0]);
-                acc[mt][1] = mma<BF>(ac[mt], bc1, acc[mt][1]);
+                acc[mt][0] = mma<BF>(aq[cur][mt], bq[cur][0], acc[mt][0]);
+                acc[mt][1] = mma<BF>(aq[cur][mt], bq[cur][1], acc[mt][1]);
             }
-            bc0 = bn0; bc1 = bn1;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ac[mt] = an[mt];
         }
     };
     // after the MFMA work of `step`: make step+1 runnable (re-stage the tile if it starts a new channel chunk, move its
     // prefetched weights registers -> idle LDS buffer), then ONE barrier
-    auto advance = [&](half8 (&wr_next)[CONV_NW], char* buf_next, int step) {
-        if (step + 1 < nsteps_) {
+    auto advance = [&](half8 (&wr_next)[NW], char* buf_next, int step) {
+        if (step + 1 < nsteps) {
             const int ch = fdiv(step, x.mg_ntaps), nch = fdiv(step + 1, x.mg_ntaps);
             if (nch != ch) {
                 __syncthreads();
@@ -224,21 +223,17 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         __syncthreads();
     };
 
-    // ---- software pipeline over (channel chunk, tap) steps.  Step s reads LDS buffer s&1; the weights of step s+1 sit in
-    //      registers (issued during step s-1) and those of step s+2 are issued now: two steps of MFMA work hide the
-    //      L2 latency of the weight stream.  One barrier per step. ----
-    char* wl1 = wl0 + wbuf_bytes;
     w_issue(wrA, 0);
-    if (nsteps_ > 1) w_issue(wrB, 1);
+    if (nsteps > 1) w_issue(wrB, 1);
     stage_tile(0);
     w_commit(wrA, wl0);
     __syncthreads();
-    for (int step = 0; step < nsteps_; step += 2) {
-        if (step + 2 < nsteps_) w_issue(wrA, step + 2);
+    for (int step = 0; step < nsteps; step += 2) {
+        if (step + 2 < nsteps) w_issue(wrA, step + 2);
         compute(wl0, step);
         advance(wrB, wl1, step);
-        if (step + 1 >= nsteps_) break;
-        if (step + 3 < nsteps_) w_issue(wrB, step + 3);
+        if (step + 1 >= nsteps) break;
+        if (step + 3 < nsteps) w_issue(wrB, step + 3);
         compute(wl1, step + 1);
         advance(wrA, wl0, step + 1);
     }
@@ -248,8 +243,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         // fp32 NCHW planar output (net_out of the last 1x1 layer: M <= 9 channels): direct stores, coalesced along x
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
-            const int n = pn[nt], y = py[nt], xx = px[nt];
-            if (n >= a.N || y >= a.H || xx >= a.W || (x.ablate & 8)) continue;
+            const int q = wave * 64 + nt * 32 + l31;
+            const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
+            const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
+            if (q >= npix || n >= a.N || y >= a.H || xx >= a.W || (x.ablate & 8)) continue;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -267,9 +264,13 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     // 16-bit NHWC output: the tile is transposed through LDS (the input tile is dead after the last barrier) so that HBM
     // sees whole 16-byte-per-lane, pixel-contiguous stores instead of 8-byte fragments of every cache line
     // (measured on the 96-channel full-resolution layers: 60-75 us of a 190 us launch were the fragmented stores).
-    const int OSTR = MT * 64 + 16;
+    constexpr int OSTR = MT * 64 + 16;
     char* ot = smem;
-    const int npix = g.TN * g.TH * g.TW;
+    // bias of this launch's channels, staged once in LDS behind the output tile (a per-lane global gather of 4*12 floats
+    // showed up as ~30 us on the 96-channel layers)
+    float* bl = reinterpret_cast<float*>(smem + (size_t)npix * OSTR);
+    if (tid < WROWS) bl[tid] = (a.bias && x.m_base + tid < a.M) ? a.bias[x.m_base + tid] : 0.f;
+    __syncthreads();
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int q = wave * 64 + nt * 32 + l31;
@@ -279,12 +280,11 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
 #pragma unroll
             for (int gq = 0; gq < 4; ++gq) {
                 const int ml = mt * 32 + gq * 8 + kh * 4;
-                const int m = x.m_base + ml;
                 float v[4];
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(bl + ml);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    v[j] = acc[mt][nt][gq * 4 + j];
-                    if (a.bias && m + j < a.M) v[j] += a.bias[m + j];
+                    v[j] = acc[mt][nt][gq * 4 + j] + bb[j];
                     if (a.act) v[j] = lrelu(v[j]);
                 }
                 if constexpr (BF) {
@@ -304,59 +304,57 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     __syncthreads();
     if (x.ablate & 8) return;
     int m_cnt = a.M - x.m_base;
-    m_cnt = m_cnt > MT * 32 ? MT * 32 : m_cnt;
+    m_cnt = m_cnt > WROWS ? WROWS : m_cnt;
     const int cpp = m_cnt >> 3;                       // 16-byte chunks per pixel
-    {
-        const unsigned mg = magic_dev(cpp);
-        for (int e = tid; e < npix * cpp; e += CONV_THREADS) {
-            const int q = mg ? __umulhi((unsigned)e, mg) : e;
-            const int c = e - q * cpp;
-            const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
-            const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
-            if (n >= a.N || y >= a.H || xx >= a.W) continue;
-            const long long pix = ((long long)n * a.H + y) * a.W + xx;
-            const int m = x.m_base + c * 8;
-            if constexpr (BF) {
-                u16x8 o = *reinterpret_cast<const u16x8*>(ot + q * OSTR + c * 16);
-                if (a.add.p || a.mask.p) {
-                    float v[8];
+    const unsigned mg = magic_dev(cpp);
+    for (int e = tid; e < npix * cpp; e += CONV_THREADS) {
+        const int q = mg ? __umulhi((unsigned)e, mg) : e;
+        const int c = e - q * cpp;
+        const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
+        const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
+        if (n >= a.N || y >= a.H || xx >= a.W) continue;
+        const long long pix = ((long long)n * a.H + y) * a.W + xx;
+        const int m = x.m_base + c * 8;
+        if constexpr (BF) {
+            u16x8 o = *reinterpret_cast<const u16x8*>(ot + q * OSTR + c * 16);
+            if (a.add.p || a.mask.p) {
+                float v[8];
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = bf2f(o[j]);
-                    if (a.add.p) {
-                        u16x8 ad = ld_b8((const unsigned short*)a.add.p + pix * a.add.cs + a.add.co + m);
+                for (int j = 0; j < 8; ++j) v[j] = bf2f(o[j]);
+                if (a.add.p) {
+                    u16x8 ad = ld_b8((const unsigned short*)a.add.p + pix * a.add.cs + a.add.co + m);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += bf2f(ad[j]);
-                    }
-                    if (a.mask.p) {
-                        half8 mk = ld_h8((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad((float)mk[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
+                    for (int j = 0; j < 8; ++j) v[j] += bf2f(ad[j]);
                 }
-                st_b8((unsigned short*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
-            } else {
-                half8 o = *reinterpret_cast<const half8*>(ot + q * OSTR + c * 16);
-                if (a.add.p || a.mask.p) {
-                    float v[8];
+                if (a.mask.p) {
+                    half8 mk = ld_h8((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (float)o[j];
-                    if (a.add.p) {
-                        half8 ad = ld_h8((const h16*)a.add.p + pix * a.add.cs + a.add.co + m);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += (float)ad[j];
-                    }
-                    if (a.mask.p) {
-                        half8 mk = ld_h8((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad((float)mk[j]);
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
+                    for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad((float)mk[j]);
                 }
-                st_h8((h16*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = f2bf(v[j]);
             }
+            st_b8((unsigned short*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
+        } else {
+            half8 o = *reinterpret_cast<const half8*>(ot + q * OSTR + c * 16);
+            if (a.add.p || a.mask.p) {
+                float v[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = (float)o[j];
+                if (a.add.p) {
+                    half8 ad = ld_h8((const h16*)a.add.p + pix * a.add.cs + a.add.co + m);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += (float)ad[j];
+                }
+                if (a.mask.p) {
+                    half8 mk = ld_h8((const h16*)a.mask.p + pix * a.mask.cs + a.mask.co + m);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad((float)mk[j]);
+                }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
+            }
+            st_h8((h16*)a.dst.p + pix * a.dst.cs + a.dst.co + m, o);
         }
     }
 }
@@ -366,13 +364,7 @@ static int conv_validate(const ssdn_conv_args* a) {
     if (a->ltw + a->lth + a->ltn > 8 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 256 pixels");
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 15)) return ssdn_set_error("conv: Ktot must equal c0+c1 and be a multiple of 16");
     if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("conv: source channel counts must be multiples of 8");
-    if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc || a->kc > 192) return ssdn_set_error("conv: kc must be a multiple of 16 (<= 192) dividing Ktot");
-    {
-        int mt = a->Mpad / 32;
-        mt = mt > 3 ? 3 : mt;
-        if (mt * 32 * (a->kc / 8) > CONV_NW * CONV_THREADS)
-            return ssdn_set_error("conv: weight slice %d x %d exceeds the prefetch registers (kc*MT <= %d)", mt * 32, a->kc, CONV_NW * CONV_THREADS / 4);
-    }
+    if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc || a->kc > 64) return ssdn_set_error("conv: kc must be 16, 32, 48 or 64 and divide Ktot");
     if ((a->Mpad & 31) || a->M > a->Mpad) return ssdn_set_error("conv: Mpad must be a multiple of 32 and >= M");
     if (!a->dst32 && ((a->M & 7) || (a->dst.co & 7) || (a->dst.cs & 7))) return ssdn_set_error("conv: 16-bit output needs M, dst.co, dst.cs %% 8 == 0");
     if (a->add.p && ((a->add.co & 7) || (a->add.cs & 7))) return ssdn_set_error("conv: add view must be 16-byte aligned");
@@ -380,7 +372,15 @@ static int conv_validate(const ssdn_conv_args* a) {
     if (a->up0 && ((a->H | a->W) & 1)) return ssdn_set_error("conv: upsampled source needs even H, W");
     if (a->c1 > 0 && !a->src1.p) return ssdn_set_error("conv: src1 missing");
     if (a->bf16 && a->dst32) return ssdn_set_error("conv: fp32 output is only implemented for the fp16 (forward) role");
+    int csmax = a->src0.cs > a->src1.cs ? a->src0.cs : a->src1.cs;
+    if ((long long)a->N * a->H * a->W * csmax >= (1ll << 31)) return ssdn_set_error("conv: tensor too large for 32-bit element offsets");
     return 0;
+}
+
+static size_t conv_lds(const ssdn_conv_args* a, const ConvGeom& g, int mt) {
+    size_t main_b = (size_t)g.NP * g.PSTR + 2 * (size_t)mt * 32 * g.WSTR;
+    size_t epi_b = a->dst32 ? 0 : (size_t)(g.TN * g.TH * g.TW) * (mt * 64 + 16) + mt * 32 * 4;
+    return main_b > epi_b ? main_b : epi_b;
 }
 
 int conv_lds_bytes(const ssdn_conv_args* a) {
@@ -388,37 +388,44 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     int mt = a->Mpad / 32;
     if (mt > 3) mt = 3;
-    int main_b = g.NP * g.PSTR + 2 * mt * 32 * g.WSTR;
-    int epi_b = a->dst32 ? 0 : (g.TN * g.TH * g.TW) * (mt * 64 + 16);
-    return main_b > epi_b ? main_b : epi_b;
+    return (int)conv_lds(a, g, mt);
 }
 
-template <int MT, bool BF>
+template <int MT, bool BF, int KS>
 static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
-    size_t lds = (size_t)g.NP * g.PSTR + 2 * (size_t)MT * 32 * g.WSTR;
-    size_t epi = a->dst32 ? 0 : (size_t)(g.TN * g.TH * g.TW) * (MT * 64 + 16);
-    lds = lds > epi ? lds : epi;
+    size_t lds = conv_lds(a, g, MT);
     if (lds > 160 * 1024) return ssdn_set_error("conv: tiling needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT, BF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT, BF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     int grid = g.tiles_x * g.tiles_y * g.groups_n;
     for (int by = 0; by < nblk_y; ++by) {
         ConvAux xx = x;
         xx.m_base = x.m_base + by * MT * 32;
-        // algorithmic work of THIS launch: real output channels x real input channels x taps x real pixels
+        // algorithmic work of THIS launch: real output channels x input channel slots x taps x real pixels
         int m_real = a->M - xx.m_base;
         m_real = m_real < 0 ? 0 : (m_real > MT * 32 ? MT * 32 : m_real);
         double px = (double)a->N * a->H * a->W;
         double flops = 2.0 * px * m_real * a->Ktot * a->ntaps;
         double bytes = px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
         prof_begin(3 - MT, s);
-        hipLaunchKernelGGL((k_conv<MT, BF>), dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
+        hipLaunchKernelGGL((k_conv<MT, BF, KS>), dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
         prof_end(3 - MT, s, flops, bytes);
     }
     return 0;
+}
+
+template <int MT, bool BF>
+static int conv_launch_ks(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
+    switch (a->kc) {
+        case 16: return conv_launch_mt<MT, BF, 1>(a, g, x, nblk_y, s);
+        case 32: return conv_launch_mt<MT, BF, 2>(a, g, x, nblk_y, s);
+        case 48: return conv_launch_mt<MT, BF, 3>(a, g, x, nblk_y, s);
+        case 64: return conv_launch_mt<MT, BF, 4>(a, g, x, nblk_y, s);
+    }
+    return ssdn_set_error("conv: unsupported kc %d", a->kc);
 }
 
 int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
@@ -428,12 +435,7 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     ConvAux x;
     x.mg_hw = magic_of(g.HW);
     x.mg_hh = magic_of(g.HH);
-    x.cc8 = a->kc / 8;
-    x.mg_cc8 = magic_of(x.cc8);
     x.mg_ntaps = magic_of(a->ntaps);
-    x.lg = 0;
-    while ((1 << x.lg) < x.cc8) ++x.lg;
-    if (x.lg > 8) return ssdn_set_error("conv: kc too large");
     x.m_base = 0;
     {
         const char* e = getenv("SSDN_CONV_ABLATE");
@@ -443,12 +445,12 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     int full = a->Mpad / 96, rem = (a->Mpad % 96) / 32;
     const bool bf = a->bf16 != 0;
     if (full) {
-        rc = bf ? conv_launch_mt<3, true>(a, g, x, full, s) : conv_launch_mt<3, false>(a, g, x, full, s);
+        rc = bf ? conv_launch_ks<3, true>(a, g, x, full, s) : conv_launch_ks<3, false>(a, g, x, full, s);
         if (rc) return rc;
     }
     x.m_base = full * 96;
-    if (rem == 2) rc = bf ? conv_launch_mt<2, true>(a, g, x, 1, s) : conv_launch_mt<2, false>(a, g, x, 1, s);
-    else if (rem == 1) rc = bf ? conv_launch_mt<1, true>(a, g, x, 1, s) : conv_launch_mt<1, false>(a, g, x, 1, s);
+    if (rem == 2) rc = bf ? conv_launch_ks<2, true>(a, g, x, 1, s) : conv_launch_ks<2, false>(a, g, x, 1, s);
+    else if (rem == 1) rc = bf ? conv_launch_ks<1, true>(a, g, x, 1, s) : conv_launch_ks<1, false>(a, g, x, 1, s);
     if (rc) return rc;
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;

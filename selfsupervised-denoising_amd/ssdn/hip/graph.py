@@ -154,7 +154,7 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
                 for kc in kcs:
                     lds = NP * (kc * 2 + 16) + 2 * mt * 32 * (kc * 2 + 16)
                     if out16:      # the output tile is transposed through the same LDS in the epilogue
-                        lds = max(lds, TN * TH * TW * (mt * 64 + 16))
+                        lds = max(lds, TN * TH * TW * (mt * 64 + 16) + mt * 128)
                     if lds > budget:
                         continue
                     halo = NP / float(TN * TH * TW)

@@ -45,6 +45,8 @@ def main():
         base = time_op(dn, op)
         print("%-18s %-5s H=%3d K=%3d M=%3d default tile (%d,%d,%d) kc=%d : %8.1f us  %7.1f TF" % (
             a["layer"], a["role"], a["H"], a["Ktot"], a["M"], 1 << a["ltw"], 1 << a["lth"], 1 << a["ltn"], a["kc"], base, flops / base / 1e6))
+        if os.environ.get("CONV_BENCH_ONLY_DEFAULT"):
+            continue
         kcs = [kc for kc in (16, 32, 48, 64, 96) if a["Ktot"] % kc == 0]
         tiles = [(5, 3, 0), (4, 4, 0), (3, 5, 0)] if a["H"] >= 32 else [(a["ltw"], a["lth"], a["ltn"])]
         for (ltw, lth, ltn), kc in itertools.product(tiles, kcs):
