@@ -142,8 +142,8 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
     padT, padB, padL, padR = _pads(taps)
     mt = min(3, Mpad // 32)
     best = None
-    # the kernel prefetches one weight slice [mt*32 rows x kc] into 3 x 16-B registers per thread (CONV_NW in conv_mfma.hip)
-    kcs = [kc for kc in range(16, min(Ktot, 192) + 1, 16) if Ktot % kc == 0 and mt * 32 * (kc // 8) <= 3 * 256]
+    # channel chunks the kernel is instantiated for (KS = kc/16 is a template parameter of k_conv)
+    kcs = [kc for kc in (16, 32, 48, 64) if Ktot % kc == 0]
     for ltw in range(0, min(5, _pow2ceil_log(W)) + 1):
         for lth in range(0, min(8 - ltw, _pow2ceil_log(H)) + 1):
             for ltn in range(0, min(8 - ltw - lth, _pow2ceil_log(N)) + 1):
