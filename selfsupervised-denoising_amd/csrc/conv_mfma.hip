@@ -130,30 +130,34 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         w_goff[i] = e < WROWS * CC8 ? ((x.m_base + m) * a.Ktot + cc * 8) : -1;
         w_loff[i] = m * STR + cc * 16;
     }
-    half8 wrA[NW], wrB[NW];
+    half8 wrA[NW], wrB[NW], wrC[NW];    // three register sets: the weight stream runs THREE steps ahead of the MFMA work
+    // every workgroup walks the taps in a different rotation: all workgroups of a launch stream the SAME 166 KB of weights,
+    // and in lock-step they would all hit the same few L2 channels with the same 9 KB slice at the same moment
+    const int rot = (x.ablate & 64) ? 0 : (int)(blockIdx.x % (unsigned)a.ntaps);
+    auto tap_of = [&](int tseq) { int t = tseq + rot; return t >= a.ntaps ? t - a.ntaps : t; };
     auto w_issue = [&](half8 (&wr)[NW], int step) {
-        if (x.ablate & 4) return;
-        const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
+        if (x.ablate & (4 | 128)) return;
+        const int ch = fdiv(step, x.mg_ntaps), t = tap_of(step - ch * a.ntaps);
         const h16* base = wp + (long long)t * a.Mpad * a.Ktot + ch * KC;
 #pragma unroll
         for (int i = 0; i < NW; ++i)
             if (w_goff[i] >= 0) wr[i] = ld_h8(base + w_goff[i]);
     };
     auto w_commit = [&](half8 (&wr)[NW], char* buf) {
-        if (x.ablate & 4) return;
+        if (x.ablate & (4 | 256)) return;
 #pragma unroll
         for (int i = 0; i < NW; ++i)
             if (w_goff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wr[i];
     };
 
-    // ---- halo tile staging: flat index f = tid + 256*j over (halo pixel, 16-B piece); 4 loads in flight per thread ----
+    // ---- halo tile staging: flat index f = tid + 256*j over (halo pixel, 16-B piece); 8 loads in flight per thread ----
     const int nflat = g.NP * CC8;
     auto stage_tile = [&](int ch) {
         if (x.ablate & 2) return;
-        for (int f0 = tid; f0 < nflat; f0 += 4 * CONV_THREADS) {
-            half8 v[4];
+        for (int f0 = tid; f0 < nflat; f0 += 8 * CONV_THREADS) {
+            half8 v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int f = f0 + u * CONV_THREADS;
                 const int hp = f / CC8, cc = f % CC8;
                 const unsigned r1 = fdiv(hp, x.mg_hw);
@@ -173,7 +177,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
                 }
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int f = f0 + u * CONV_THREADS;
                 if (f < nflat) *reinterpret_cast<half8*>(tile + (f / CC8) * STR + (f % CC8) * 16) = v[u];
             }
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     // ---- one pipeline step on the matrix cores: KS K-steps, fully unrolled, ping-pong fragments, immediate offsets ----
     auto compute = [&](const char* wl, int step) {
         if (x.ablate & 1) return;
-        const int ch = fdiv(step, x.mg_ntaps), t = step - ch * a.ntaps;
+        const int ch = fdiv(step, x.mg_ntaps), t = tap_of(step - ch * a.ntaps);
         const int toff = (a.dy[t] * g.HW + a.dx[t]) * STR;
         const char* b0p = tile + bbase[0] + toff;
         const char* b1p = tile + bbase[1] + toff;
@@ -220,24 +224,44 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             }
             w_commit(wr_next, buf_next);
         }
-        __syncthreads();
+        if (!(x.ablate & 32)) __syncthreads();
     };
 
+    // buffers alternate wl0 / wl1 by step parity; register sets rotate A, B, C by step mod 3.
+    // invariant at the top of step s: LDS buffer s&1 holds W(s); W(s+1), W(s+2) are in flight in their register sets.
     w_issue(wrA, 0);
     if (nsteps > 1) w_issue(wrB, 1);
+    if (nsteps > 2) w_issue(wrC, 2);
     stage_tile(0);
     w_commit(wrA, wl0);
     __syncthreads();
-    for (int step = 0; step < nsteps; step += 2) {
-        if (step + 2 < nsteps) w_issue(wrA, step + 2);
+    for (int step = 0; step < nsteps; step += 6) {
+        if (step + 3 < nsteps) w_issue(wrA, step + 3);
         compute(wl0, step);
         advance(wrB, wl1, step);
         if (step + 1 >= nsteps) break;
-        if (step + 3 < nsteps) w_issue(wrB, step + 3);
+        if (step + 4 < nsteps) w_issue(wrB, step + 4);
         compute(wl1, step + 1);
-        advance(wrA, wl0, step + 1);
+        advance(wrC, wl0, step + 1);
+        if (step + 2 >= nsteps) break;
+        if (step + 5 < nsteps) w_issue(wrC, step + 5);
+        compute(wl0, step + 2);
+        advance(wrA, wl1, step + 2);
+        if (step + 3 >= nsteps) break;
+        if (step + 6 < nsteps) w_issue(wrA, step + 6);
+        compute(wl1, step + 3);
+        advance(wrB, wl0, step + 3);
+        if (step + 4 >= nsteps) break;
+        if (step + 7 < nsteps) w_issue(wrB, step + 7);
+        compute(wl0, step + 4);
+        advance(wrC, wl1, step + 4);
+        if (step + 5 >= nsteps) break;
+        if (step + 8 < nsteps) w_issue(wrC, step + 8);
+        compute(wl1, step + 5);
+        advance(wrA, wl0, step + 5);
     }
 
+    if (x.ablate & 16) return;
     // ---- epilogue: D row = 8*(r>>2) + 4*(lane>>5) + (r&3)  (output channel), D col = lane&31 (pixel) -------------
     if (a.dst32) {
         // fp32 NCHW planar output (net_out of the last 1x1 layer: M <= 9 channels): direct stores, coalesced along x

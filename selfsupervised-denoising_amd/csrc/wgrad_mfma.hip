@@ -66,8 +66,8 @@ static inline unsigned magic_ofw(unsigned d) { return d <= 1 ? 0u : (unsigned)((
 
 struct WgAux {
     unsigned mg_hw, mg_hh;
-    int lgx, ccx;  // staging of the input tile: 2^lgx threads per pixel, ccx 16-B chunks
-    int lgd, ccd;  // staging of the dZ tile
+    int ccx, ccd;             // 16-B pieces per pixel of the input tile / of the dZ tile
+    unsigned mg_ccx, mg_ccd;  // their magic reciprocals
 };
 
 template <int MT, int CPW>
@@ -124,43 +124,66 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
         const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
         const int n0 = bid * g.TN, y0 = ty_i * g.TH, x0 = tx_i * g.TW;
         __syncthreads();  // previous tile fully consumed
-        {   // ---- stage input halo tile ----
-            const int G = 1 << x.lgx, sub = tid & (G - 1), grp = tid >> x.lgx, ngrp = WG_THREADS >> x.lgx;
-            if (sub < x.ccx) {
-                const int k = sub * 8;
-                for (int hp = grp; hp < g.NP; hp += ngrp) {
-                    unsigned r1 = fdivw(hp, x.mg_hw);
-                    int hx = hp - r1 * g.HW;
-                    unsigned tn = fdivw(r1, x.mg_hh);
-                    int hy = r1 - tn * g.HH;
-                    int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
-                    half8 v = zero_h8();
-                    if (n < a.N && y >= 0 && y < a.H && xx >= 0 && xx < a.W) {
+        {   // ---- stage input halo tile: flat index over (halo pixel, 16-B piece), 4 independent loads in flight per thread
+            //      (a load -> convert -> store chain per iteration made the staging a sequence of full memory round trips) ----
+            const int nflat = g.NP * x.ccx;
+            for (int f0 = tid; f0 < nflat; f0 += 4 * WG_THREADS) {
+                half8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * WG_THREADS;
+                    const int hp = fdivw(f, x.mg_ccx), cc = f - hp * x.ccx;
+                    const unsigned r1 = fdivw(hp, x.mg_hw);
+                    const int hx = hp - r1 * g.HW;
+                    const unsigned tn = fdivw(r1, x.mg_hh);
+                    const int hy = r1 - tn * g.HH;
+                    const int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
+                    const int k = cc * 8;
+                    v[u] = zero_h8();
+                    if (f < nflat && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
                         if (k < a.c0) {
-                            int ys = a.up0 ? (y >> 1) : y, xs = a.up0 ? (xx >> 1) : xx;
-                            v = ld_h8(s0 + (((long long)n * H0 + ys) * W0 + xs) * a.src0.cs + a.src0.co + k);
+                            const int sh = a.up0;
+                            v[u] = ld_h8(s0 + (long long)(((n * H0 + (y >> sh)) * W0 + (xx >> sh)) * a.src0.cs + a.src0.co + k));
                         } else {
-                            v = ld_h8(s1 + (((long long)n * a.H + y) * a.W + xx) * a.src1.cs + a.src1.co + (k - a.c0));
+                            v[u] = ld_h8(s1 + (long long)(((n * a.H + y) * a.W + xx) * a.src1.cs + a.src1.co + (k - a.c0)));
                         }
                     }
-                    // fp16 activation -> bf16 once, while staging (the gradient operand is bf16; MFMA needs one type)
-                    u16x8 vb;
+                }
 #pragma unroll
-                    for (int e = 0; e < 8; ++e) vb[e] = f2bf((float)v[e]);
-                    *reinterpret_cast<u16x8*>(xt + (size_t)hp * g.PSTR + sub * 16) = vb;
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * WG_THREADS;
+                    if (f < nflat) {
+                        const int hp = fdivw(f, x.mg_ccx), cc = f - hp * x.ccx;
+                        // fp16 activation -> bf16 once, while staging (the gradient operand is bf16; MFMA needs one type)
+                        u16x8 vb;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) vb[e] = f2bf((float)v[u][e]);
+                        *reinterpret_cast<u16x8*>(xt + (size_t)hp * g.PSTR + cc * 16) = vb;
+                    }
                 }
             }
         }
         {   // ---- stage dZ tile (zero outside the image so overhanging pixels contribute nothing) ----
-            const int G = 1 << x.lgd, sub = tid & (G - 1), grp = tid >> x.lgd, ngrp = WG_THREADS >> x.lgd;
-            if (sub < x.ccd) {
-                for (int q = grp; q < npix_tile; q += ngrp) {
-                    int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
-                    int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
-                    half8 v = zero_h8();
-                    if (n < a.N && y < a.H && xx < a.W)
-                        v = ld_h8(dzp + (((long long)n * a.H + y) * a.W + xx) * a.dz.cs + a.dz.co + sub * 8);
-                    *reinterpret_cast<half8*>(dt + (size_t)q * g.DSTR + sub * 16) = v;
+            const int nflat = npix_tile * x.ccd;
+            for (int f0 = tid; f0 < nflat; f0 += 4 * WG_THREADS) {
+                half8 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * WG_THREADS;
+                    const int q = fdivw(f, x.mg_ccd), cc = f - q * x.ccd;
+                    const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
+                    const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
+                    v[u] = zero_h8();
+                    if (f < nflat && n < a.N && y < a.H && xx < a.W)
+                        v[u] = ld_h8(dzp + (long long)(((n * a.H + y) * a.W + xx) * a.dz.cs + a.dz.co + cc * 8));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int f = f0 + u * WG_THREADS;
+                    if (f < nflat) {
+                        const int q = fdivw(f, x.mg_ccd), cc = f - q * x.ccd;
+                        *reinterpret_cast<half8*>(dt + (size_t)q * g.DSTR + cc * 16) = v[u];
+                    }
                 }
             }
         }
@@ -263,11 +286,9 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     x.mg_hw = magic_ofw(g.HW);
     x.mg_hh = magic_ofw(g.HH);
     x.ccx = a->Ktot / 8;
-    x.lgx = 0;
-    while ((1 << x.lgx) < x.ccx) ++x.lgx;
     x.ccd = a->M / 8;
-    x.lgd = 0;
-    while ((1 << x.lgd) < x.ccd) ++x.lgd;
+    x.mg_ccx = magic_ofw(x.ccx);
+    x.mg_ccd = magic_ofw(x.ccd);
     const int MT = a->Mpad / 32;
     const int CT = a->ntaps * (a->Kpad / 32) + 1;
     const int CPW = (CT + 7) / 8;
