@@ -64,13 +64,13 @@ enum ssdn_op_type {
 };
 
 /* One record of the op list.  `args` points at the matching ssdn_*_args struct (host memory).
- * lane 0: the op is enqueued on the caller's stream.  lane 1: on a library-owned side stream, AFTER everything that
- * precedes it in the list on lane 0 (the executor inserts the hipEvent dependency); lane-0 ops never wait for lane 1
- * inside a list, but ssdn_run_ops joins the side stream back into the caller's stream before it returns.  The planner
- * guarantees the absence of WAR/WAW hazards between the lanes (lane 1 carries the weight-gradient GEMMs + slab
- * reductions of the backward pass: they only read tensors that are written once per step, and write the slab scratch and
- * the flat gradient, which lane 0 does not touch) -- so small, latency-bound backward launches overlap instead of
- * queueing behind each other. */
+ * lane 0: the op is enqueued on the caller's stream.  lane k = 1, 2: on a library-owned side stream, AFTER everything that
+ * precedes it in the list on lanes 0..k-1 (the executor inserts the hipEvent dependencies); a lane never waits for a higher
+ * lane inside a list, but ssdn_run_ops joins all side streams back into the caller's stream before it returns.  The planner
+ * guarantees the absence of WAR/WAW hazards between lanes: lane 1 carries the weight-gradient GEMMs of the backward pass
+ * (they read tensors written once per step and write their OWN slab), lane 2 the slab reductions (they read that slab and
+ * write the flat gradient, which nothing else touches) -- so the many small, latency-bound backward launches overlap instead
+ * of queueing behind each other. */
 typedef struct ssdn_op {
     int32_t type;
     int32_t lane;

@@ -194,7 +194,8 @@ class Interp:
         out[..., :C] = gg.permute(0, 2, 3, 1)
         self.store(dst, cpad, out)
 
-    def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, coff, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn):
+    def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, coff, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn,
+                 slab=None, bslab=None):
         x = _r16(self._gather(src0, src1, c0, c1, up0, N, H, W), self.fp16, "bf16")   # staged as bf16 on the device
         g = self.view(dz, M)
         self.slab = torch.zeros(len(taps), Mpad, Kpad)
@@ -204,7 +205,8 @@ class Interp:
         self.bslab = torch.zeros(Mpad)
         self.bslab[:M] = g.sum((0, 1, 2))
 
-    def op_wreduce(self, layer, nslabs, ntaps, M, Mpad, Kpad, cin, cin_full, m_off, c_off, with_bias, tapblock=0):
+    def op_wreduce(self, layer, nslabs, ntaps, M, Mpad, Kpad, cin, cin_full, m_off, c_off, with_bias, tapblock=0,
+                   slab=None, bslab=None):
         l = self.L[layer]
         base = self.plan.param_base
         gw = self.grads[base + l.w_off: base + l.w_off + l.M * l.cin * l.ntaps].reshape(l.M, l.cin, l.ntaps)

@@ -119,41 +119,49 @@ int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* f
 int ssdn_conv_lds_bytes(const ssdn_conv_args* a) { return conv_lds_bytes(a); }
 int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a) { return wgrad_lds_bytes(a); }
 
-#define SSDN_NEVENTS 64
-static hipStream_t g_side = nullptr;
+#define SSDN_NEVENTS 256
+#define SSDN_NLANES 3
+static hipStream_t g_side[SSDN_NLANES] = {nullptr, nullptr, nullptr};   // [0] unused (= caller's stream)
 static hipEvent_t g_ev[SSDN_NEVENTS];
 static int g_ev_next = 0;
 static bool g_lanes_ready = false;
 static int lanes_init() {
     if (g_lanes_ready) return 0;
-    SSDN_CHECK_HIP(hipStreamCreateWithFlags(&g_side, hipStreamNonBlocking));
+    for (int l = 1; l < SSDN_NLANES; ++l) SSDN_CHECK_HIP(hipStreamCreateWithFlags(&g_side[l], hipStreamNonBlocking));
     for (int i = 0; i < SSDN_NEVENTS; ++i) SSDN_CHECK_HIP(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
     g_lanes_ready = true;
     return 0;
 }
 
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
-    hipStream_t main_s = (hipStream_t)stream;
-    bool main_dirty = true, side_used = false;   // main_dirty: lane 0 has work the side stream has not been ordered after
+    hipStream_t lane_s[SSDN_NLANES] = {(hipStream_t)stream, nullptr, nullptr};
+    // dirty[l]: lane l has enqueued work that lane l+1 has not been ordered after yet
+    bool dirty[SSDN_NLANES] = {true, false, false}, used[SSDN_NLANES] = {true, false, false};
     static const bool one_lane = getenv("SSDN_ONE_LANE") != nullptr;   // tuning / debugging aid
     for (int i = 0; i < n; ++i) {
         const void* p = ops[i].args;
         int rc = 0;
         if (!p) return ssdn_set_error("op %d: null args", i);
-        hipStream_t s = main_s;
-        if (ops[i].lane == 1 && !one_lane) {
+        int lane = one_lane ? 0 : ops[i].lane;
+        if (lane < 0 || lane >= SSDN_NLANES) return ssdn_set_error("op %d: bad lane %d", i, lane);
+        if (lane > 0) {
             if (lanes_init()) return -1;
-            if (main_dirty) {
-                hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
-                SSDN_CHECK_HIP(hipEventRecord(e, main_s));
-                SSDN_CHECK_HIP(hipStreamWaitEvent(g_side, e, 0));
-                main_dirty = false;
+            lane_s[1] = g_side[1];
+            lane_s[2] = g_side[2];
+            // lane k runs after everything that precedes it in the list on lanes 0..k-1: chain the pending orderings upwards
+            for (int l = 0; l < lane; ++l) {
+                if (dirty[l]) {
+                    hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
+                    SSDN_CHECK_HIP(hipEventRecord(e, lane_s[l]));
+                    SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[l + 1], e, 0));
+                    dirty[l] = false;
+                    if (l + 1 < lane) dirty[l + 1] = true;   // the wait itself must propagate to the next lane up
+                }
             }
-            s = g_side;
-            side_used = true;
-        } else {
-            main_dirty = true;
         }
+        dirty[lane] = true;
+        used[lane] = true;
+        hipStream_t s = lane_s[lane];
         switch (ops[i].type) {
             case SSDN_OP_PACK_INPUT: rc = launch_pack_input((const ssdn_pack_input_args*)p, s); break;
             case SSDN_OP_CONV: rc = launch_conv((const ssdn_conv_args*)p, s); break;
@@ -190,10 +198,11 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             return ssdn_set_error("op %d (type %d): %s", i, ops[i].type, tmp);
         }
     }
-    if (side_used) {   // join
+    for (int l = 1; l < SSDN_NLANES; ++l) {   // join every side lane back into the caller's stream
+        if (!used[l]) continue;
         hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
-        SSDN_CHECK_HIP(hipEventRecord(e, g_side));
-        SSDN_CHECK_HIP(hipStreamWaitEvent(main_s, e, 0));
+        SSDN_CHECK_HIP(hipEventRecord(e, lane_s[l]));
+        SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[0], e, 0));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ssdn_set_error("launch error: %s", hipGetErrorString(e));

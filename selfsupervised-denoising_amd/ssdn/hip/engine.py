@@ -21,7 +21,7 @@ def _ptr(t: torch.Tensor, byte_off: int = 0) -> int:
 class OpList:
     """A materialised op list: a ctypes array of ssdn_op plus the argument structs it points to."""
 
-    SIDE_LANE = ("wgrad", "wreduce")     # weight-gradient GEMMs + slab reductions run on the library's side stream
+    LANE = {"wgrad": 1, "wreduce": 2}    # weight-gradient GEMMs / slab reductions run on the library's side streams
 
     def __init__(self, recs, lanes: bool = False):
         self.args = [r[1] for r in recs]                      # keep the structs alive
@@ -29,7 +29,7 @@ class OpList:
         for i, r in enumerate(recs):
             ty, a = r[0], r[1]
             self.arr[i].type = L.OP[ty]
-            self.arr[i].lane = 1 if (lanes and ty in self.SIDE_LANE) else 0
+            self.arr[i].lane = self.LANE.get(ty, 0) if lanes else 0
             self.arr[i].args = C.cast(C.pointer(a), C.c_void_p)
         self.n = len(recs)
 
@@ -123,7 +123,7 @@ class DeviceNet:
                 s.dy[i], s.dx[i] = dy, dx
                 s.coff[i] = a["coff"][i]
             s.M, s.Mpad, s.Ktot, s.Kpad = a["M"], a["Mpad"], a["Ktot"], a["Kpad"]
-            s.slab, s.bslab = _ptr(self.t[P + "slab"]), _ptr(self.t[P + "bslab"])
+            s.slab, s.bslab = _ptr(self.t[a["slab"]]), _ptr(self.t[a["bslab"]])
             s.nslabs = a["nslabs"]
             s.ltw, s.lth, s.ltn = a["ltw"], a["lth"], a["ltn"]
             if L.load().ssdn_wgrad_lds_bytes(C.byref(s)) < 0:
@@ -131,7 +131,7 @@ class DeviceNet:
             return op.type, s
         if op.type == "wreduce":
             l = self._layer(a["layer"])
-            return op.type, L.WreduceArgs(_ptr(self.t[P + "slab"]), _ptr(self.t[P + "bslab"]), a["nslabs"], a["ntaps"], a["M"],
+            return op.type, L.WreduceArgs(_ptr(self.t[a["slab"]]), _ptr(self.t[a["bslab"]]), a["nslabs"], a["ntaps"], a["M"],
                                           a["Mpad"], a["Kpad"], a["cin"], a["cin_full"], a["m_off"], a["c_off"], a["tapblock"],
                                           self._gp(l.w_off), self._gp(l.b_off) if a["with_bias"] else None,
                                           _ptr(self.t[P + "scale"], 4))
