@@ -21,7 +21,6 @@
 #include "common.h"
 #include <cstdlib>
 
-#define CONV_THREADS 256
 
 struct ConvGeom {
     int TW, TH, TN, HH, HW, padT, padB, padL, padR;
@@ -60,7 +59,13 @@ struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_ntaps;      // magic reciprocal of ntaps
     int m_base;             // first output channel of this launch (multiple of 32)
     int ablate;             // tuning aid (env SSDN_CONV_ABLATE): 1 no MFMA, 2 no tile staging, 4 no weight stream, 8 no stores
+    unsigned long long* trace;   // tuning aid (ssdn_debug_set_trace): 32 s_memtime stamps per workgroup, or NULL
+    int desync;             // first-round workgroups start (hash(block) & 7) * desync * 8128 cycles late (0 = off)
 };
+
+static unsigned long long* g_conv_trace = nullptr;
+extern "C" void ssdn_debug_set_trace(void* p) { g_conv_trace = (unsigned long long*)p; }
+extern "C" void* ssdn_debug_get_trace() { return g_conv_trace; }
 
 template <bool BF>
 static __device__ __forceinline__ f32x16 mma(half8 av, half8 bv, f32x16 c) {
@@ -72,8 +77,10 @@ static __device__ __forceinline__ f32x16 mma(half8 av, half8 bv, f32x16 c) {
 
 // BF = false: fp16 operands / fp16 output (forward);  BF = true: bf16 operands / bf16 output (data gradient).
 // Tiles are moved through LDS as raw 16-bit words, so only the MFMA opcode and the epilogue conversions differ.
-// KS = channel chunk / 16 (K-steps per pipeline step).
-template <int MT, bool BF, int KS>
+// KS = channel chunk / 16 (K-steps per pipeline step).  CONV_THREADS = 256 (4 waves, tile <= 256 pixels) or 512 (8 waves,
+// tile <= 512 pixels): every workgroup streams the whole weight tensor through the CU's vector-memory path once per tile, and
+// on the 96-channel layers that stream (166 KB per tile) outweighs the activations -- the wide variant halves it per pixel.
+template <int MT, bool BF, int KS, int CONV_THREADS>
 __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, ConvAux x) {
     constexpr int KC = KS * 16;            // channels per chunk
     constexpr int CC8 = KS * 2;            // 16-byte pieces per pixel / weight row
@@ -101,7 +108,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     for (int nt = 0; nt < 2; ++nt) {
         int q = wave * 64 + nt * 32 + l31;
         int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
-        if (tn >= g.TN) tn = ty = tx = 0;   // tile smaller than 256 pixels: surplus lanes compute on pixel 0, store nothing
+        if (tn >= g.TN) tn = ty = tx = 0;   // tile smaller than the workgroup: surplus lanes compute on pixel 0, store nothing
         bbase[nt] = ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * STR + kh * 16;
     }
     const int abase = l31 * STR + kh * 16;
@@ -114,6 +121,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][nt][r] = 0.f;
 
+    int tr_i = 0;
+    auto stamp = [&]() {
+        if (x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
+    };
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
     const int nchunks = a.Ktot / KC;
     const int nsteps = nchunks * a.ntaps;
@@ -127,8 +138,10 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     for (int i = 0; i < NW; ++i) {
         const int e = tid + i * CONV_THREADS;
         const int m = e / CC8, cc = e % CC8;
-        w_goff[i] = e < WROWS * CC8 ? ((x.m_base + m) * a.Ktot + cc * 8) : -1;
-        w_loff[i] = m * STR + cc * 16;
+        // threads without an element in slot i still LOAD (element 0, discarded): unconditional, branch-free loads are what
+        // lets the compiler count outstanding loads (s_waitcnt vmcnt(N)) instead of draining the whole queue (vmcnt(0))
+        w_goff[i] = e < WROWS * CC8 ? ((x.m_base + m) * a.Ktot + cc * 8) : x.m_base * a.Ktot;
+        w_loff[i] = e < WROWS * CC8 ? m * STR + cc * 16 : -1;
     }
     half8 wrA[NW], wrB[NW], wrC[NW];    // three register sets: the weight stream runs THREE steps ahead of the MFMA work
     // every workgroup walks the taps in a different rotation: all workgroups of a launch stream the SAME 166 KB of weights,
@@ -136,18 +149,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     const int rot = (x.ablate & 64) ? 0 : (int)(blockIdx.x % (unsigned)a.ntaps);
     auto tap_of = [&](int tseq) { int t = tseq + rot; return t >= a.ntaps ? t - a.ntaps : t; };
     auto w_issue = [&](half8 (&wr)[NW], int step) {
-        if (x.ablate & (4 | 128)) return;
+        step = step < nsteps ? step : nsteps - 1;      // past the end: re-load the last slice (never committed)
         const int ch = fdiv(step, x.mg_ntaps), t = tap_of(step - ch * a.ntaps);
         const h16* base = wp + (long long)t * a.Mpad * a.Ktot + ch * KC;
 #pragma unroll
-        for (int i = 0; i < NW; ++i)
-            if (w_goff[i] >= 0) wr[i] = ld_h8(base + w_goff[i]);
+        for (int i = 0; i < NW; ++i) wr[i] = ld_h8(base + w_goff[i]);
     };
     auto w_commit = [&](half8 (&wr)[NW], char* buf) {
-        if (x.ablate & (4 | 256)) return;
 #pragma unroll
         for (int i = 0; i < NW; ++i)
-            if (w_goff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wr[i];
+            if (w_loff[i] >= 0) *reinterpret_cast<half8*>(buf + w_loff[i]) = wr[i];
     };
 
     // ---- halo tile staging: flat index f = tid + 256*j over (halo pixel, 16-B piece); 8 loads in flight per thread ----
@@ -225,38 +236,45 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             w_commit(wr_next, buf_next);
         }
         if (!(x.ablate & 32)) __syncthreads();
+        stamp();
     };
 
     // buffers alternate wl0 / wl1 by step parity; register sets rotate A, B, C by step mod 3.
     // invariant at the top of step s: LDS buffer s&1 holds W(s); W(s+1), W(s+2) are in flight in their register sets.
+    if (x.desync && blockIdx.x < 512) {
+        const int k = (int)((blockIdx.x * 2654435761u) >> 29) * x.desync;
+        for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+    stamp();
     w_issue(wrA, 0);
-    if (nsteps > 1) w_issue(wrB, 1);
-    if (nsteps > 2) w_issue(wrC, 2);
+    w_issue(wrB, 1);
+    w_issue(wrC, 2);
     stage_tile(0);
     w_commit(wrA, wl0);
     __syncthreads();
+    stamp();
     for (int step = 0; step < nsteps; step += 6) {
-        if (step + 3 < nsteps) w_issue(wrA, step + 3);
+        w_issue(wrA, step + 3);
         compute(wl0, step);
         advance(wrB, wl1, step);
         if (step + 1 >= nsteps) break;
-        if (step + 4 < nsteps) w_issue(wrB, step + 4);
+        w_issue(wrB, step + 4);
         compute(wl1, step + 1);
         advance(wrC, wl0, step + 1);
         if (step + 2 >= nsteps) break;
-        if (step + 5 < nsteps) w_issue(wrC, step + 5);
+        w_issue(wrC, step + 5);
         compute(wl0, step + 2);
         advance(wrA, wl1, step + 2);
         if (step + 3 >= nsteps) break;
-        if (step + 6 < nsteps) w_issue(wrA, step + 6);
+        w_issue(wrA, step + 6);
         compute(wl1, step + 3);
         advance(wrB, wl0, step + 3);
         if (step + 4 >= nsteps) break;
-        if (step + 7 < nsteps) w_issue(wrB, step + 7);
+        w_issue(wrB, step + 7);
         compute(wl0, step + 4);
         advance(wrC, wl1, step + 4);
         if (step + 5 >= nsteps) break;
-        if (step + 8 < nsteps) w_issue(wrC, step + 8);
+        w_issue(wrC, step + 8);
         compute(wl1, step + 5);
         advance(wrA, wl0, step + 5);
     }
@@ -326,6 +344,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         }
     }
     __syncthreads();
+    stamp();
     if (x.ablate & 8) return;
     int m_cnt = a.M - x.m_base;
     m_cnt = m_cnt > WROWS ? WROWS : m_cnt;
@@ -388,11 +407,12 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             st_h8((h16*)a.dst.p + pixs[u] * a.dst.cs + a.dst.co + m, o);      // raw 16-bit words (fp16 or bf16)
         }
     }
+    stamp();
 }
 
 static int conv_validate(const ssdn_conv_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("conv: ntaps out of range");
-    if (a->ltw + a->lth + a->ltn > 8 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 256 pixels");
+    if (a->ltw + a->lth + a->ltn > 9 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 512 pixels");
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 15)) return ssdn_set_error("conv: Ktot must equal c0+c1 and be a multiple of 16");
     if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("conv: source channel counts must be multiples of 8");
     if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc || a->kc > 64) return ssdn_set_error("conv: kc must be 16, 32, 48 or 64 and divide Ktot");
@@ -422,13 +442,13 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
     return (int)conv_lds(a, g, mt);
 }
 
-template <int MT, bool BF, int KS>
+template <int MT, bool BF, int KS, int CONV_THREADS>
 static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
     size_t lds = conv_lds(a, g, MT);
     if (lds > 160 * 1024) return ssdn_set_error("conv: tiling needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT, BF, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT, BF, KS, CONV_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     int grid = g.tiles_x * g.tiles_y * g.groups_n;
@@ -442,7 +462,7 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
         double flops = 2.0 * px * m_real * a->Ktot * a->ntaps;
         double bytes = px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
         prof_begin(3 - MT, s);
-        hipLaunchKernelGGL((k_conv<MT, BF, KS>), dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
+        hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
         prof_end(3 - MT, s, flops, bytes);
     }
     return 0;
@@ -450,11 +470,12 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
 
 template <int MT, bool BF>
 static int conv_launch_ks(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
+    const bool wide = a->ltw + a->lth + a->ltn > 8;     // 257..512-pixel tiles run with 8 waves
     switch (a->kc) {
-        case 16: return conv_launch_mt<MT, BF, 1>(a, g, x, nblk_y, s);
-        case 32: return conv_launch_mt<MT, BF, 2>(a, g, x, nblk_y, s);
-        case 48: return conv_launch_mt<MT, BF, 3>(a, g, x, nblk_y, s);
-        case 64: return conv_launch_mt<MT, BF, 4>(a, g, x, nblk_y, s);
+        case 16: return wide ? conv_launch_mt<MT, BF, 1, 512>(a, g, x, nblk_y, s) : conv_launch_mt<MT, BF, 1, 256>(a, g, x, nblk_y, s);
+        case 32: return wide ? conv_launch_mt<MT, BF, 2, 512>(a, g, x, nblk_y, s) : conv_launch_mt<MT, BF, 2, 256>(a, g, x, nblk_y, s);
+        case 48: return wide ? conv_launch_mt<MT, BF, 3, 512>(a, g, x, nblk_y, s) : conv_launch_mt<MT, BF, 3, 256>(a, g, x, nblk_y, s);
+        case 64: return wide ? conv_launch_mt<MT, BF, 4, 512>(a, g, x, nblk_y, s) : conv_launch_mt<MT, BF, 4, 256>(a, g, x, nblk_y, s);
     }
     return ssdn_set_error("conv: unsupported kc %d", a->kc);
 }
@@ -471,6 +492,9 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     {
         const char* e = getenv("SSDN_CONV_ABLATE");
         x.ablate = e ? atoi(e) : 0;
+        x.trace = g_conv_trace;
+        e = getenv("SSDN_CONV_DESYNC");
+        x.desync = e ? atoi(e) : 0;
     }
     // output channels in launches of 96 (MT=3); the tail uses MT = 1 or 2
     int full = a->Mpad / 96, rem = (a->Mpad % 96) / 32;

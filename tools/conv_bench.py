@@ -47,8 +47,10 @@ def main():
             a["layer"], a["role"], a["H"], a["Ktot"], a["M"], 1 << a["ltw"], 1 << a["lth"], 1 << a["ltn"], a["kc"], base, flops / base / 1e6))
         if os.environ.get("CONV_BENCH_ONLY_DEFAULT"):
             continue
-        kcs = [kc for kc in (16, 32, 48, 64, 96) if a["Ktot"] % kc == 0]
-        tiles = [(5, 3, 0), (4, 4, 0), (3, 5, 0)] if a["H"] >= 32 else [(a["ltw"], a["lth"], a["ltn"])]
+        kcs = [kc for kc in (32, 48, 64) if a["Ktot"] % kc == 0]
+        tiles = [(4, 4, 0), (5, 4, 0), (4, 5, 0)] if a["H"] >= 32 else [(a["ltw"], a["lth"], a["ltn"])]
+        if len(a["taps"]) == 1:
+            tiles = [(5, 0, 3), (5, 0, 4)]
         for (ltw, lth, ltn), kc in itertools.product(tiles, kcs):
             o = Op("conv", dict(a))
             o.a.update(ltw=ltw, lth=lth, ltn=ltn, kc=kc)
@@ -60,5 +62,50 @@ def main():
             print("      tile (%2d,%2d,%d) kc=%3d : %8.1f us  %7.1f TF" % (1 << ltw, 1 << lth, 1 << ltn, kc, t, flops / t / 1e6))
 
 
+
+
+def trace(layer="decode_block_1.2", role="fwd"):
+    """per-workgroup phase timeline from s_memtime stamps (ssdn_debug_set_trace)"""
+    import ctypes as C
+    import numpy as np
+    B, P = 32, 64
+    lib = L.load()
+    plan = NetPlan("m/", 3, 9, True, B, P, P, cus=lib.ssdn_device_cus())
+    dev = torch.device("cuda:0")
+    flat = torch.randn(plan.nparams, device=dev) * 0.05
+    dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+    for name, t in dn.t.items():
+        if t.dtype in (torch.float16, torch.bfloat16):
+            t.copy_(torch.randn(t.shape, device=dev) * 0.5)
+    dn.pack.run(current_stream())
+    if role == "wgrad":
+        op = [o for o in plan.bwd if o.type == "wgrad" and o.a["layer"] == layer][0]
+    else:
+        op = [o for o in plan.fwd + plan.bwd if o.type == "conv" and o.a["layer"] == layer and o.a["role"] == role][0]
+    ol = OpList([dn._mat(op)])
+    for _ in range(3):
+        ol.run(current_stream())
+    buf = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
+    lib.ssdn_debug_set_trace.argtypes = [C.c_void_p]
+    lib.ssdn_debug_set_trace(C.c_void_p(buf.data_ptr()))
+    ol.run(current_stream())
+    torch.cuda.synchronize()
+    lib.ssdn_debug_set_trace(None)
+    t = buf.cpu().view(-1, 32).numpy()
+    t = t[t[:, 0] > 0]
+    t0 = t[:, 0].min()
+    nst = int((t[0] > 0).sum())
+    d = np.diff(t[:, :nst], axis=1)
+    print("workgroups traced", len(t), "stamps per WG", nst)
+    print("median phase durations (ticks):", [int(v) for v in np.median(d, axis=0)])
+    st = np.sort(t[:, 0]) - t0
+    print("WG start times: 0..15:", [int(v) for v in st[:16]], " #512:", int(st[min(512, len(st) - 1)]), " #1024:", int(st[min(1024, len(st) - 1)]), " last:", int(st[-1]), " last end:", int(t[:, nst - 1].max() - t0))
+    tot = t[:, nst - 1] - t[:, 0]
+    print("per-WG total ticks: median %d min %d max %d" % (np.median(tot), tot.min(), tot.max()))
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "trace":
+        trace(*(sys.argv[2:4]))
+    else:
+        main()
