@@ -7,15 +7,25 @@
 // the forward kernel) and both MFMA operands are fetched with the LDS transpose-read.  No transposed copy of any
 // activation or gradient is ever written to HBM.
 //
-// Work split: workgroup = 512 threads = 8 waves, persistent over its share of 256-pixel tiles.  For one launch the
-// output is [ntaps][Mpad<=96][Kpad<=96] (+ a bias column): ntaps*Kpad/32 (+1) column tiles of 32, dealt round-robin to
-// the 8 waves (<= CPW per wave), each wave keeping MT x CPW 32x32 fp32 accumulators in registers for the whole pixel
-// range and reading the dZ operand (A) once per K-step for all its column tiles.  At the end every workgroup writes its
-// accumulators to its own fp32 slab (plain coalesced stores, no atomics) and SSDN_OP_WREDUCE sums the slabs in a fixed
-// order => bit-reproducible gradients.
+// Work split: workgroup = 256 threads = 4 waves (one per SIMD), persistent over its share of (<=256-pixel) tiles that are
+// double-buffered in LDS.  For one launch the output is [ntaps][Mpad<=96][Kpad<=96] (+ a bias column): ntaps*Kpad/32 (+1)
+// column tiles of 32, dealt round-robin to the 4 waves (<= CPW <= 7 per wave), each wave keeping MT x CPW 32x32 fp32
+// accumulators in registers for the whole pixel range and reading the dZ operand (A) once per K-step for all its column
+// tiles.  At the end every workgroup writes its accumulators to its own fp32 slab (plain coalesced stores, no atomics) and
+// SSDN_OP_WREDUCE sums the slabs in a fixed order => bit-reproducible gradients.
 #include "common.h"
+#include <type_traits>
 
-#define WG_THREADS 512
+template <int I, int N, class F>
+static __device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+#define WG_THREADS 256
+#define WG_WAVES 4
 
 typedef __attribute__((__vector_size__(4 * sizeof(__fp16)))) __fp16 fp16x4_t;
 typedef __attribute__((address_space(3))) fp16x4_t lds_fp16x4;
@@ -36,8 +46,10 @@ static __device__ __forceinline__ half8 cat8(half4 lo, half4 hi) {
 
 struct WgGeom {
     int TW, TH, TN, HH, HW, padT, padL, NP, PSTR, DSTR;
+    int XB, DB;   // bytes of the input / dZ part of one LDS image (each with one extra dummy row that absorbs void row items)
     int tiles_x, tiles_y, groups_n, ntiles;
 };
+static __host__ __device__ constexpr int wg_stride(int row_bytes) { return ((row_bytes + 63) & ~127) + 64; }
 static __host__ __device__ inline WgGeom wg_geom(const ssdn_wgrad_args& a) {
     WgGeom g;
     g.TW = 1 << a.ltw; g.TH = 1 << a.lth; g.TN = 1 << a.ltn;
@@ -52,8 +64,12 @@ static __host__ __device__ inline WgGeom wg_geom(const ssdn_wgrad_args& a) {
     g.NP = g.TN * g.HH * g.HW;
     int kmax = a.Ktot;          // channels a transpose-read may touch: staged ones + the (harmless, never used) padding
     for (int t = 0; t < a.ntaps; ++t) kmax = a.coff[t] + a.Kpad > kmax ? a.coff[t] + a.Kpad : kmax;
-    g.PSTR = kmax * 2 + 16;
-    g.DSTR = a.Mpad * 2 + 16;
+    // pixel strides of the LDS images: == 64 (mod 128) bytes, so that the 4 pixels x 64 bytes a 32-lane half of a transpose
+    // read touches fall on 4 disjoint groups of 16 banks (a stride of row-bytes + 16 was 2-way bank conflicted)
+    g.PSTR = wg_stride(kmax * 2);
+    g.DSTR = wg_stride(a.Mpad * 2);
+    g.XB = (g.NP + g.HW) * g.PSTR;
+    g.DB = (g.TN * g.TH * g.TW + g.TW) * g.DSTR;
     g.tiles_x = (a.W + g.TW - 1) / g.TW;
     g.tiles_y = (a.H + g.TH - 1) / g.TH;
     g.groups_n = (a.N + g.TN - 1) / g.TN;
@@ -61,21 +77,79 @@ static __host__ __device__ inline WgGeom wg_geom(const ssdn_wgrad_args& a) {
     return g;
 }
 
-static __device__ __forceinline__ unsigned fdivw(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
+// x / d for d >= 1 with magic = ceil(2^32 / d) (0 when d == 1), branch-free: umulhi(x, 0) + x when d == 1
+static __device__ __forceinline__ unsigned fdivw(unsigned x, unsigned magic) {
+    return __umulhi(x, magic) + (x & (unsigned)-(int)(magic == 0));
+}
+typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2_t;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2_t;
+// 8 fp16 -> 8 bf16 (v_cvt_f32_f16 x2 + v_cvt_pk_bf16_f32 per pair, round-to-nearest-even)
+static __device__ __forceinline__ half8 cvt_h8_to_bf8(half8 v) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f32x2_t f = {(float)v[2 * i], (float)v[2 * i + 1]};
+        w[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+    }
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+    u32x4_t r = {w[0], w[1], w[2], w[3]};
+    return __builtin_bit_cast(half8, r);
+}
+static __device__ __forceinline__ half8 mask_h8(half8 v, bool keep) {
+    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+    u32x4_t r = __builtin_bit_cast(u32x4_t, v);
+    const unsigned m = (unsigned)-(int)keep;
+    r[0] &= m; r[1] &= m; r[2] &= m; r[3] &= m;
+    return __builtin_bit_cast(half8, r);
+}
 static inline unsigned magic_ofw(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 
+extern "C" void* ssdn_debug_get_trace();
 struct WgAux {
-    unsigned mg_hw, mg_hh;
+    unsigned long long* trace;
     int ccx, ccd;             // 16-B pieces per pixel of the input tile / of the dZ tile
-    unsigned mg_ccx, mg_ccd;  // their magic reciprocals
+    unsigned mg_ccx, mg_ccd;  // their magic reciprocals (per-lane: piece of a row -> pixel, chunk)
+    unsigned mg_hh;           // scalar: halo row -> (image of the tile, halo y)
+    int rswx, rswd;           // rows of the input halo image / of the dZ image each wave stages per tile
 };
 
-template <int MT, int CPW>
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+#define SSDN_BUFFER_RSRC_FLAGS 0x00020000   // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
+#define WG_ND 3                             // 64-lane loads per dZ row (<= 16 pixels x 12 chunks)
+
+// MFMA with the accumulator pinned to a register file.  A wave of this kernel owns up to 21 32x32 fp32 accumulators = 336
+// registers, more than the 256 AGPRs: the first 16 tiles live in AGPRs, the rest in VGPRs (the compiler will not split
+// them itself -- it spills instead).  The compiler does not know these asm statements are MFMAs, so it inserts no hazard
+// NOPs: the operands are only ever written by LDS reads (s_waitcnt is tracked per register, asm or not), an accumulator is
+// re-used every MT*CPW >= 18 MFMAs, and the epilogue reads the accumulators after a barrier and explicit NOPs.
+template <int FILE>   // 0: compiler's choice (builtin), 1: AGPR, 2: VGPR
+static __device__ __forceinline__ void mma_bf16(f32x16& c, half8 av, half8 bv) {
+    if constexpr (FILE == 0) {
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+    } else if constexpr (FILE == 1) {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(av), "v"(bv));
+    } else {
+        asm("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(av), "v"(bv));
+    }
+}
+
+// One wave per SIMD (256-thread workgroup, 4 waves): each wave may use the full 512-entry unified VGPR/AGPR file, which is
+// what holding up to MT*CPW = 21 accumulators PLUS double-buffered operand fragments PLUS the in-flight global prefetch
+// takes.  With a single wave per SIMD nothing hides instruction ISSUE (measured: ~10 cycles per instruction), so the loop is
+// written for instruction count: a K-step is 21 MFMAs + 20 LDS transpose reads + ~40 instructions of staging.
+//
+// Staging: a ROW ITEM is one image row of the tile (input halo row or dZ row), loaded by NL (resp. 3) 64-lane
+// buffer_load_dwordx4.  Everything about the row (image, y, validity, base address) is wave-uniform and computed on the
+// scalar unit into a buffer resource whose num_records is the row length, so the hardware bounds check returns zeros for the
+// left/right halo (negative or too large x offset) and for rows above/below the image (num_records = 0); the per-lane part
+// (pixel-in-row, channel chunk) -> global byte offset and LDS byte offset is computed ONCE per kernel.  The rows of a tile are
+// dealt to the 4 waves; a wave issues one row item per K-step (BOTH: one input and one dZ row) and writes it to the other
+// LDS image two K-steps later.
+template <int MT, int CPW, int NL, bool BOTH, int PS, int KS, int RWX, int RWD>
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr bool SPLIT = MT * CPW > 16;         // accumulators do not fit the AGPR file
     const WgGeom g = wg_geom(a);
-    char* xt = smem;                           // input halo tile  [NP][PSTR]
-    char* dt = smem + (size_t)g.NP * g.PSTR;   // dZ tile          [256][DSTR]
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -83,18 +157,157 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     const int NTt = a.Kpad >> 5;
     const int CT = a.ntaps * NTt;  // column tiles; tile index CT = the bias column
 
-    // column tiles of this wave
+    // column tiles of this wave: ct = wave + 4 j.  Tiles j < CPW-1 always exist and are weight columns (4 (CPW-1) <= CT);
+    // only the last one can be the bias column (its B operand is the constant 1, never refilled) or absent.
     int ct_tap[CPW], ct_nt[CPW];
     bool ct_on[CPW], ct_bias[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-        int ct = wave + 8 * j;
+        int ct = wave + WG_WAVES * j;
         ct_on[j] = ct <= CT;
         ct_bias[j] = ct == CT;
         int tp = ct_on[j] && !ct_bias[j] ? ct / NTt : 0;
         ct_tap[j] = tp;
         ct_nt[j] = ct_on[j] && !ct_bias[j] ? ct - tp * NTt : 0;
     }
+    int stoff[CPW];   // wave-uniform LDS byte offset of the column tile's (tap, 32-channel block) relative to a halo pixel
+#pragma unroll
+    for (int j = 0; j < CPW; ++j)
+        stoff[j] = (a.dy[ct_tap[j]] * g.HW + a.dx[ct_tap[j]]) * g.PSTR + (a.coff[ct_tap[j]] + ct_nt[j] * 32) * 2;
+    const bool last_on = ct_on[CPW - 1], last_bias = ct_bias[CPW - 1];
+
+    // the input of one launch comes from ONE tensor (src0, optionally read through the 2x nearest upsampling, or src1)
+    const bool use0 = a.c0 > 0;
+    const h16* sp = (const h16*)(use0 ? a.src0.p : a.src1.p);
+    const int scs = use0 ? a.src0.cs : a.src1.cs, sco = use0 ? a.src0.co : a.src1.co, sh = use0 ? a.up0 : 0;
+    const int Hs = a.H >> sh, Ws = a.W >> sh;
+    const h16* dzp = (const h16*)a.dz.p;
+    const int npix_tile = g.TN * g.TH * g.TW;
+    const int RX = g.TN * g.HH, RD = g.TN * g.TH;         // rows of the input halo image / of the dZ image
+    const int rowx = g.HW * x.ccx, rowd = g.TW * x.ccd;   // 16-B pieces per row
+
+    // per-lane constants of the row loads: global byte offset relative to (row start + tile x origin) and LDS byte offset
+    // relative to the row's first pixel.  Lanes past the end of the row repeat the load and the LDS write of an earlier piece
+    // of the same row (same address, same data).
+    int relx[NL], lox[NL], reld[WG_ND], lod[WG_ND];
+#pragma unroll
+    for (int i = 0; i < NL; ++i) {
+        int j = lane + 64 * i;
+        j = j < rowx ? j : j % rowx;
+        const int hx = fdivw(j, x.mg_ccx), cc = j - hx * x.ccx;
+        relx[i] = ((((hx - g.padL) >> sh) * scs) + sco + cc * 8) * 2;
+        lox[i] = hx * g.PSTR + cc * 16;
+    }
+#pragma unroll
+    for (int i = 0; i < WG_ND; ++i) {
+        int j = lane + 64 * i;
+        j = j < rowd ? j : j % rowd;
+        const int tx = fdivw(j, x.mg_ccd), cc = j - tx * x.ccd;
+        reld[i] = (tx * a.dz.cs + a.dz.co + cc * 8) * 2;
+        lod[i] = tx * g.DSTR + cc * 16;
+    }
+
+    int tr_i = 0;
+    auto stamp = [&]() {
+        if (x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
+    };
+    stamp();
+    // ---- double-buffered pipeline over this workgroup's tiles -------------------------------------------------------
+    const int bufsz = g.XB + g.DB;
+    const int ksteps = npix_tile >> 4;
+    const int ntl = ((int)g.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+
+    auto origin = [&](int i, int& n0, int& y0, int& x0) __attribute__((always_inline)) {
+        int bid = blockIdx.x + i * gridDim.x;
+        const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
+        const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
+        n0 = bid * g.TN; y0 = ty_i * g.TH; x0 = tx_i * g.TW;
+    };
+    // ---- row items ---------------------------------------------------------------------------------------------------
+    // scalar description of one row: buffer base / length, x origin byte offset, LDS byte offset of the row (-1: no item)
+    struct Row { const h16* base; int num, xs, lds; };
+    auto row_x = [&](int rs, bool live, int n0, int y0, int x0) __attribute__((always_inline)) -> Row {
+        const int row = wave + WG_WAVES * rs;
+        const int tn = fdivw(row, x.mg_hh), hy = row - tn * g.HH;
+        const int n = n0 + tn, y = y0 - g.padT + hy;
+        const bool item = live && rs < x.rswx && row < RX;
+        const bool rowok = item && n < a.N && (unsigned)y < (unsigned)a.H;
+        Row r;
+        r.base = sp + (long long)((n * Hs + (y >> sh)) * Ws) * scs;
+        r.num = rowok ? Ws * scs * 2 : 0;
+        r.xs = ((x0 >> sh) * scs) * 2;
+        r.lds = item ? row * g.HW * g.PSTR : -1;
+        return r;
+    };
+    auto row_d = [&](int rs, bool live, int n0, int y0, int x0) __attribute__((always_inline)) -> Row {
+        const int row = wave + WG_WAVES * rs;
+        const int tn = row >> a.lth, ty = row & (g.TH - 1);
+        const int n = n0 + tn, y = y0 + ty;
+        const bool item = live && rs < x.rswd && row < RD;
+        const bool rowok = item && n < a.N && y < a.H;
+        Row r;
+        r.base = dzp + (long long)((n * a.H + y) * a.W) * a.dz.cs;
+        r.num = rowok ? a.W * a.dz.cs * 2 : 0;
+        r.xs = x0 * a.dz.cs * 2;
+        r.lds = item ? g.XB + row * g.TW * g.DSTR : -1;
+        return r;
+    };
+    auto load16 = [&](const Row& r, int rel) __attribute__((always_inline)) -> half8 {
+        __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)r.base, 0, r.num, SSDN_BUFFER_RSRC_FLAGS);
+        return __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rsrc, rel + r.xs, 0, 0));
+    };
+    // fp16 activation -> bf16 once, while staging (the gradient operand is bf16; MFMA needs one type)
+    auto put_x = [&](char* img, int rowlds, int i, half8 v) __attribute__((always_inline)) {
+        *reinterpret_cast<half8*>(img + rowlds + lox[i]) = cvt_h8_to_bf8(v);
+    };
+    auto put_d = [&](char* img, int rowlds, int i, half8 v) __attribute__((always_inline)) {
+        *reinterpret_cast<half8*>(img + rowlds + lod[i]) = v;
+    };
+
+    // prefetch register sets by K-step parity (prefetch distance 2 K-steps).  !BOTH: one row item per K-step, input rows
+    // first, then dZ rows, sharing the registers; BOTH: an input row and a dZ row per K-step.
+    constexpr int NPV = BOTH ? NL + WG_ND : (NL > WG_ND ? NL : WG_ND);
+    const int nit = BOTH ? (x.rswx > x.rswd ? x.rswx : x.rswd) : x.rswx + x.rswd;   // row items per wave per tile
+
+    if (ntl > 0) {   // first image: synchronous, PB row items in flight
+        constexpr int PB = BOTH ? 3 : 6;
+        int n0, y0, x0;
+        origin(0, n0, y0, x0);
+        for (int r0 = 0; r0 < nit; r0 += PB) {
+            half8 tv[PB][NPV];
+            int tl[PB], td[PB];
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int r = r0 + u;
+                tl[u] = td[u] = -1;
+                if (BOTH || r < x.rswx) {
+                    const Row rw = row_x(r, r < nit, n0, y0, x0);
+                    tl[u] = rw.lds;
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) tv[u][i] = load16(rw, relx[i]);
+                }
+                if (BOTH || r >= x.rswx) {
+                    const Row rw = row_d(BOTH ? r : r - x.rswx, r < nit, n0, y0, x0);
+                    td[u] = rw.lds;
+#pragma unroll
+                    for (int i = 0; i < WG_ND; ++i) tv[u][(BOTH ? NL : 0) + i] = load16(rw, reld[i]);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                if (tl[u] >= 0) {
+#pragma unroll
+                    for (int i = 0; i < NL; ++i) put_x(smem, tl[u], i, tv[u][i]);
+                }
+                if (td[u] >= 0) {
+#pragma unroll
+                    for (int i = 0; i < WG_ND; ++i) put_d(smem, td[u], i, tv[u][(BOTH ? NL : 0) + i]);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    stamp();
 
     f32x16 acc[MT][CPW];
 #pragma unroll
@@ -104,126 +317,234 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
 
-    half8 ones;   // bf16 1.0 = 0x3f80 in every 16-bit slot
+    half8 pvA[NPV], pvB[NPV];
+    int rlA = -1, rlB = -1, rdA = -1, rdB = -1;   // LDS row offsets of the items in flight (-1: none); rd*: dZ item
+#pragma unroll
+    for (int u = 0; u < NPV; ++u) pvA[u] = pvB[u] = zero_h8();
+
+    // operand fragments: A (dZ, MT row tiles) double-buffered by K-step parity, B (input, CPW column tiles) refilled in place
+    // right after the MFMAs that consumed it -- every LDS transpose read is issued one full K-step before its use.
+    half8 afA[MT], afB[MT], bf[CPW];
     {
-        u16x8 o;
+        u16x8 o;   // bf16 1.0 = 0x3f80 in every 16-bit slot: the B operand of the bias column
 #pragma unroll
         for (int i = 0; i < 8; ++i) o[i] = 0x3f80;
-        ones = __builtin_bit_cast(half8, o);
+        bf[CPW - 1] = __builtin_bit_cast(half8, o);
+    }
+    // per-lane part of the fragment addresses: the two pixels (of the 16 of a K-step) this lane supplies to the transpose
+    // reads (r = 0,1 -> k elements 0..3 / 4..7); the K-step's first pixel adds a wave-uniform offset
+    // (a K-step's 16 pixels are whole rows of one image, or whole images: tiles are <= 16 wide and all sizes powers of 2)
+    int dlane[2], xlane[2];
+#pragma unroll
+    for (int r = 0; r < 2; ++r) {
+        const int e = kh * 8 + r * 4 + (i16 >> 2);
+        const int tx = e & (g.TW - 1), tyl = (e >> a.ltw) & (g.TH - 1), tnl = e >> (a.ltw + a.lth);
+        dlane[r] = e * g.DSTR + (i16 & 3) * 8;
+        xlane[r] = ((tnl * g.HH + tyl) * g.HW + tx + g.padL) * g.PSTR + (i16 & 3) * 8;
     }
 
-    const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
-    const h16* s0 = (const h16*)a.src0.p;
-    const h16* s1 = (const h16*)a.src1.p;
-    const h16* dzp = (const h16*)a.dz.p;
-    const int npix_tile = g.TN * g.TH * g.TW;
+    for (int i = 0; i < ntl; ++i) {
+        const char* xt_c = smem + (i & 1) * bufsz;
+        const char* dt_c = xt_c + g.XB;
+        char* img_n = smem + ((i + 1) & 1) * bufsz;
+        const bool more = i + 1 < ntl;   // the last tile prefetches nothing
+        int n0 = 0, y0 = 0, x0 = 0;
+        if (more) origin(i + 1, n0, y0, x0);
 
-    for (int tile = blockIdx.x; tile < g.ntiles; tile += gridDim.x) {
-        int bid = tile;
-        const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
-        const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
-        const int n0 = bid * g.TN, y0 = ty_i * g.TH, x0 = tx_i * g.TW;
-        __syncthreads();  // previous tile fully consumed
-        {   // ---- stage input halo tile: flat index over (halo pixel, 16-B piece), 4 independent loads in flight per thread
-            //      (a load -> convert -> store chain per iteration made the staging a sequence of full memory round trips) ----
-            const int nflat = g.NP * x.ccx;
-            for (int f0 = tid; f0 < nflat; f0 += 4 * WG_THREADS) {
-                half8 v[4];
+        // fragment addresses: ONE vector add per K-step for A and one per column tile for B; everything else is either
+        // wave-uniform (scalar unit) or a compile-time constant folded into the ds_read offset field (DSTR follows from MT;
+        // PS > 0 is the compile-time input pixel stride -- the lane's second pixel is 4 pixels further in the same row)
+        constexpr int DS_C = wg_stride(MT * 64);
+        auto abase = [&](int ks) __attribute__((always_inline)) -> const char* { return dt_c + (ks << 4) * DS_C + (dlane[0] + mh * 32); };
+        auto read_a1 = [&](const char* ab, int mt) __attribute__((always_inline)) -> half8 {
+            return cat8(tr16(ab + mt * 64), tr16(ab + 4 * DS_C + mt * 64));
+        };
+        auto xbase = [&](int ks) __attribute__((always_inline)) -> const char* {
+            const int q0 = ks << 4;                              // first pixel of the K-step
+            const int tn = q0 >> (a.ltw + a.lth), ty = (q0 >> a.ltw) & (g.TH - 1);
+            return xt_c + ((tn * g.HH + ty + g.padT) * g.HW) * g.PSTR;
+        };
+        auto read_b = [&](const char* xb, int j) __attribute__((always_inline)) -> half8 {
+            const char* p0 = (xb + stoff[j]) + (xlane[0] + mh * 32);
+            if constexpr (PS > 0) return cat8(tr16(p0), tr16(p0 + 4 * PS));
+            else return cat8(tr16(p0), tr16((xb + stoff[j]) + (xlane[1] + mh * 32)));
+        };
+        auto mma = [&](auto Jc, auto Mc, const half8* afc) __attribute__((always_inline)) {
+            constexpr int j = decltype(Jc)::value, mt = decltype(Mc)::value;
+            if constexpr (!SPLIT) mma_bf16<0>(acc[mt][j], afc[mt], bf[j]);
+            else if constexpr (j * MT + mt < 16) mma_bf16<1>(acc[mt][j], afc[mt], bf[j]);
+            else mma_bf16<2>(acc[mt][j], afc[mt], bf[j]);
+        };
+        // One K-step = MT*CPW "slots", each one MFMA plus a slice of the side work.  A wave issues in order: a second MFMA
+        // cannot issue while the matrix pipe is busy (32 cycles), and nothing behind it can either -- so the side work is
+        // spread BETWEEN the MFMAs (~5 instructions per slot) instead of after them, and sched_barrier pins that order:
+        //   slots 0..MT-1       : A fragments of the next K-step
+        //   last slot of column j: refill B fragment j for the next K-step
+        //   then, evenly spaced : write the NPV pieces of the row loaded two K-steps ago to the other LDS image, describe the
+        //                         next row on the scalar unit, issue its NPV loads.
+        // The last K-step "prefetches" the fragments of K-step 0 of the SAME image (wrapped index; they are re-read from the
+        // next image after the barrier).
+        auto step = [&](int ks, half8* afc, half8* afn, half8* pv, int& rl, int& rd) __attribute__((always_inline)) {
+            const int kn = (ks + 1) & (ksteps - 1);
+            const char* ab = abase(kn);
+            const char* xb = xbase(kn);
+            if constexpr (BOTH) {
+                if (rl >= 0) {
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int f = f0 + u * WG_THREADS;
-                    const int hp = fdivw(f, x.mg_ccx), cc = f - hp * x.ccx;
-                    const unsigned r1 = fdivw(hp, x.mg_hw);
-                    const int hx = hp - r1 * g.HW;
-                    const unsigned tn = fdivw(r1, x.mg_hh);
-                    const int hy = r1 - tn * g.HH;
-                    const int n = n0 + tn, y = y0 - g.padT + hy, xx = x0 - g.padL + hx;
-                    const int k = cc * 8;
-                    v[u] = zero_h8();
-                    if (f < nflat && n < a.N && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W) {
-                        if (k < a.c0) {
-                            const int sh = a.up0;
-                            v[u] = ld_h8(s0 + (long long)(((n * H0 + (y >> sh)) * W0 + (xx >> sh)) * a.src0.cs + a.src0.co + k));
-                        } else {
-                            v[u] = ld_h8(s1 + (long long)(((n * a.H + y) * a.W + xx) * a.src1.cs + a.src1.co + (k - a.c0)));
+                    for (int u = 0; u < NL; ++u) put_x(img_n, rl, u, pv[u]);
+                }
+                if (rd >= 0) {
+#pragma unroll
+                    for (int u = 0; u < WG_ND; ++u) put_d(img_n, rd, u, pv[NL + u]);
+                }
+                const Row rx = row_x(ks, more, n0, y0, x0), rw = row_d(ks, more, n0, y0, x0);
+                rl = rx.lds; rd = rw.lds;
+#pragma unroll
+                for (int u = 0; u < NL; ++u) pv[u] = load16(rx, relx[u]);
+#pragma unroll
+                for (int u = 0; u < WG_ND; ++u) pv[NL + u] = load16(rw, reld[u]);
+            }
+            constexpr int SLOTS = MT * CPW, NSIDE = 2 * NPV + 1;
+            const h16* nbase = dzp;   // the row issued in this K-step (!BOTH)
+            int nnum = 0, nxs = 0;
+            bool nisx = false;
+            static_for<0, SLOTS>([&](auto Sc) __attribute__((always_inline)) {
+                constexpr int S = decltype(Sc)::value, j = S / MT, mt = S % MT;
+                if (j < CPW - 1 || last_on) mma(std::integral_constant<int, j>{}, std::integral_constant<int, mt>{}, afc);
+                if constexpr (S < MT) afn[S] = read_a1(ab, S);
+                if constexpr (mt == MT - 1) {
+                    if (j < CPW - 1 || !last_bias) bf[j] = read_b(xb, j);
+                }
+                if constexpr (!BOTH) {
+                    // side item w lives in slot MT + w * (SLOTS - MT) / NSIDE (all in the last slot when there are few slots)
+                    static_for<0, NSIDE>([&](auto Wc) __attribute__((always_inline)) {
+                        constexpr int w = decltype(Wc)::value;
+                        constexpr int sl = SLOTS - MT >= NSIDE ? MT + w * (SLOTS - MT) / NSIDE : SLOTS - 1;
+                        if constexpr (sl == S) {
+                            if constexpr (w < NPV) {            // write piece w of the row loaded two K-steps ago
+                                if (rl >= 0) { if constexpr (w < NL) put_x(img_n, rl, w, pv[w]); }
+                                else if (rd >= 0) { if constexpr (w < WG_ND) put_d(img_n, rd, w, pv[w]); }
+                            } else if constexpr (w == NPV) {     // describe the next row
+                                nisx = ks < x.rswx;
+                                // (one formula with selected parameters: no control flow, no values through memory)
+                                const int rs = nisx ? ks : ks - x.rswx;
+                                const int row = wave + WG_WAVES * rs;
+                                const bool item = more && rs < (nisx ? x.rswx : x.rswd) && row < (nisx ? RX : RD);
+                                const int tn = nisx ? (int)fdivw(row, x.mg_hh) : row >> a.lth;
+                                const int hy = row - tn * (nisx ? g.HH : g.TH);
+                                const int n = n0 + tn, y = y0 + hy - (nisx ? g.padT : 0);
+                                const int shx = nisx ? sh : 0, csx = nisx ? scs : a.dz.cs;
+                                const int Hh = nisx ? Hs : a.H, Ww = nisx ? Ws : a.W;
+                                const bool rowok = item && n < a.N && (unsigned)y < (unsigned)a.H;
+                                nbase = (nisx ? sp : dzp) + (long long)((n * Hh + (y >> shx)) * Ww) * csx;
+                                nnum = rowok ? Ww * csx * 2 : 0;
+                                nxs = ((x0 >> shx) * csx) * 2;
+                                const int lds = item ? (nisx ? row * g.HW * g.PSTR : g.XB + row * g.TW * g.DSTR) : -1;
+                                rl = nisx ? lds : -1;
+                                rd = nisx ? -1 : lds;
+                            } else {                             // issue load w - NPV - 1 of it
+                                constexpr int u = w - NPV - 1;
+                                Row nrow;
+                                nrow.base = nbase; nrow.num = nnum; nrow.xs = nxs; nrow.lds = 0;
+                                int relv = (int)0x80000000, relw = (int)0x80000000;
+                                if constexpr (u < NL) relv = relx[u];
+                                if constexpr (u < WG_ND) relw = reld[u];
+                                pv[u] = load16(nrow, nisx ? relv : relw);
+                            }
                         }
-                    }
+                    });
                 }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+        };
+
+        {   // fragments of K-step 0 (the image became visible at the barrier just passed)
+            const char* ab = abase(0);
+            const char* xb = xbase(0);
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int f = f0 + u * WG_THREADS;
-                    if (f < nflat) {
-                        const int hp = fdivw(f, x.mg_ccx), cc = f - hp * x.ccx;
-                        // fp16 activation -> bf16 once, while staging (the gradient operand is bf16; MFMA needs one type)
-                        u16x8 vb;
+            for (int mt = 0; mt < MT; ++mt) afA[mt] = read_a1(ab, mt);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) vb[e] = f2bf((float)v[u][e]);
-                        *reinterpret_cast<u16x8*>(xt + (size_t)hp * g.PSTR + cc * 16) = vb;
+            for (int j = 0; j < CPW; ++j)
+                if (j < CPW - 1 || !last_bias) bf[j] = read_b(xb, j);
+        }
+        if constexpr (KS > 0) {
+            // ---- static schedule (hot shapes: one image per tile, KS K-steps, RWX input + RWD dZ rows per wave) -------------
+            // The K loop is fully unrolled and every K-step knows at compile time what it loads (K-step ks loads row item ks:
+            // input rows first, then dZ rows) and what it writes to LDS (the item of K-step ks-2): no branches, no selects.  A
+            // wave whose row index is past the tile (the row count need not divide by 4) loads zeros and writes them to the
+            // image's dummy row.
+            const int xsx = ((x0 >> sh) * scs) * 2, xsd = x0 * a.dz.cs * 2;
+            static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {
+                constexpr int ks = decltype(Kc)::value;
+                constexpr int LK = ks < RWX ? 1 : ks < RWX + RWD ? 2 : 0;                       // loaded in this K-step
+                constexpr int CK = ks < 2 ? 0 : ks - 2 < RWX ? 1 : ks - 2 < RWX + RWD ? 2 : 0;    // committed in this K-step
+                half8* afc = (ks & 1) ? afB : afA;
+                half8* afn = (ks & 1) ? afA : afB;
+                half8* pv = (ks & 1) ? pvB : pvA;
+                int& ro = (ks & 1) ? rlB : rlA;          // LDS byte offset (inside an image) of the set's row
+                constexpr int kn = (ks + 1) % KS;
+                const char* ab = abase(kn);
+                const char* xb = xbase(kn);
+                const h16* nbase = dzp;
+                int nnum = 0;
+                constexpr int SLOTS = MT * CPW, NSIDE = 2 * NPV + 1;
+                static_for<0, SLOTS>([&](auto Sc) __attribute__((always_inline)) {
+                    constexpr int S = decltype(Sc)::value, j = S / MT, mt = S % MT;
+                    if (j < CPW - 1 || last_on) mma(std::integral_constant<int, j>{}, std::integral_constant<int, mt>{}, afc);
+                    if constexpr (S < MT) afn[S] = read_a1(ab, S);
+                    if constexpr (mt == MT - 1) {
+                        if (j < CPW - 1 || !last_bias) bf[j] = read_b(xb, j);
                     }
-                }
+                    static_for<0, NSIDE>([&](auto Wc) __attribute__((always_inline)) {
+                        constexpr int w = decltype(Wc)::value;
+                        constexpr int sl = SLOTS - MT >= NSIDE ? MT + w * (SLOTS - MT) / NSIDE : SLOTS - 1;
+                        if constexpr (sl == S) {
+                            if constexpr (w < NPV) {
+                                if constexpr (CK == 1 && w < NL) put_x(img_n, ro, w, pv[w]);
+                                if constexpr (CK == 2 && w < WG_ND) put_d(img_n, ro, w, pv[w]);
+                            } else if constexpr (w == NPV) {
+                                if constexpr (LK == 1) {
+                                    const int row = wave + WG_WAVES * ks;
+                                    const bool valid = row < g.HH;
+                                    const int y = y0 - g.padT + row;
+                                    const bool ok = more && valid && (unsigned)y < (unsigned)a.H;
+                                    nbase = sp + (long long)((n0 * Hs + (y >> sh)) * Ws) * scs;
+                                    nnum = ok ? Ws * scs * 2 : 0;
+                                    ro = (valid ? row : g.HH) * g.HW * g.PSTR;
+                                } else if constexpr (LK == 2) {
+                                    const int row = wave + WG_WAVES * (ks - RWX);
+                                    const bool valid = row < g.TH;
+                                    const int y = y0 + row;
+                                    const bool ok = more && valid && y < a.H;
+                                    nbase = dzp + (long long)((n0 * a.H + y) * a.W) * a.dz.cs;
+                                    nnum = ok ? a.W * a.dz.cs * 2 : 0;
+                                    ro = g.XB + (valid ? row : g.TH) * g.TW * g.DSTR;
+                                }
+                            } else {
+                                constexpr int u = w - NPV - 1;
+                                Row nrow;
+                                nrow.base = nbase; nrow.num = nnum; nrow.lds = 0;
+                                if constexpr (LK == 1 && u < NL) { nrow.xs = xsx; pv[u] = load16(nrow, relx[u]); }
+                                if constexpr (LK == 2 && u < WG_ND) { nrow.xs = xsd; pv[u] = load16(nrow, reld[u]); }
+                            }
+                        }
+                    });
+                    __builtin_amdgcn_sched_barrier(0);
+                });
+            });
+        } else {
+#pragma unroll 1
+            for (int ks = 0; ks < ksteps; ks += 2) {   // ksteps is even (tiles have >= 32 pixels)
+                step(ks, afA, afB, pvA, rlA, rdA);
+                step(ks + 1, afB, afA, pvB, rlB, rdB);
             }
         }
-        {   // ---- stage dZ tile (zero outside the image so overhanging pixels contribute nothing) ----
-            const int nflat = npix_tile * x.ccd;
-            for (int f0 = tid; f0 < nflat; f0 += 4 * WG_THREADS) {
-                half8 v[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int f = f0 + u * WG_THREADS;
-                    const int q = fdivw(f, x.mg_ccd), cc = f - q * x.ccd;
-                    const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
-                    const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
-                    v[u] = zero_h8();
-                    if (f < nflat && n < a.N && y < a.H && xx < a.W)
-                        v[u] = ld_h8(dzp + (long long)(((n * a.H + y) * a.W + xx) * a.dz.cs + a.dz.co + cc * 8));
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const int f = f0 + u * WG_THREADS;
-                    if (f < nflat) {
-                        const int q = fdivw(f, x.mg_ccd), cc = f - q * x.ccd;
-                        *reinterpret_cast<half8*>(dt + (size_t)q * g.DSTR + cc * 16) = v[u];
-                    }
-                }
-            }
-        }
-        __syncthreads();
-        // ---- K loop over the tile's pixels, 16 per step ----
-        for (int q0 = 0; q0 < npix_tile; q0 += 16) {
-            // the two pixels this lane addresses for the transpose reads (r = 0,1 -> k elements 0..3 / 4..7)
-            int dofs[2], xofs[2];
-#pragma unroll
-            for (int r = 0; r < 2; ++r) {
-                int q = q0 + kh * 8 + r * 4 + (i16 >> 2);
-                if (q >= npix_tile) q = 0;  // tiles with < 16 pixels per step cannot occur (npix_tile is a multiple of 16 or handled by host)
-                int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
-                dofs[r] = q * g.DSTR + (i16 & 3) * 8;
-                xofs[r] = ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * g.PSTR + (i16 & 3) * 8;
-            }
-            half8 af[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                const int cofs = (mt * 32 + mh * 16) * 2;
-                af[mt] = cat8(tr16(dt + dofs[0] + cofs), tr16(dt + dofs[1] + cofs));
-            }
-#pragma unroll
-            for (int j = 0; j < CPW; ++j) {
-                if (!ct_on[j]) continue;
-                half8 bf;
-                if (ct_bias[j]) {
-                    bf = ones;
-                } else {
-                    const int toff = (a.dy[ct_tap[j]] * g.HW + a.dx[ct_tap[j]]) * g.PSTR + (a.coff[ct_tap[j]] + ct_nt[j] * 32 + mh * 16) * 2;
-                    bf = cat8(tr16(xt + xofs[0] + toff), tr16(xt + xofs[1] + toff));
-                }
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[mt][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, bf),
-                                                                         acc[mt][j], 0, 0, 0);
-            }
-        }
+        __syncthreads();   // image i fully consumed by every wave, image i+1 complete
+        stamp();
     }
 
+    stamp();
+    if constexpr (SPLIT) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // ---- write this workgroup's slab: D row = m (8*(r>>2) + 4*kh + (r&3)), D col = k (l31) ----
     float* slab = a.slab + (long long)blockIdx.x * a.ntaps * a.Mpad * a.Kpad;
 #pragma unroll
@@ -246,7 +567,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
 
 static int wgrad_validate(const ssdn_wgrad_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("wgrad: ntaps out of range");
-    if (a->ltw + a->lth + a->ltn > 8 || a->ltw + a->lth + a->ltn < 4) return ssdn_set_error("wgrad: tile must have 16..256 pixels");
+    if (a->ltw + a->lth + a->ltn > 8 || a->ltw + a->lth + a->ltn < 5) return ssdn_set_error("wgrad: tile must have 32..256 pixels");
+    if (a->ltw > 4) return ssdn_set_error("wgrad: tiles are at most 16 pixels wide");
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 7)) return ssdn_set_error("wgrad: Ktot must equal c0+c1 (multiple of 8)");
     if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("wgrad: source channel counts must be multiples of 8");
     if ((a->Kpad & 31) || a->Kpad > 96) return ssdn_set_error("wgrad: Kpad must be 32/64/96");
@@ -254,26 +576,48 @@ static int wgrad_validate(const ssdn_wgrad_args* a) {
         if (a->coff[t] < 0 || (a->coff[t] & 15) || a->coff[t] >= a->Ktot) return ssdn_set_error("wgrad: bad channel offset of tap %d", t);
     if ((a->Mpad & 31) || a->Mpad > 96 || a->M > a->Mpad || (a->M & 7)) return ssdn_set_error("wgrad: Mpad must be 32/64/96, M %% 8 == 0");
     if (a->nslabs < 1) return ssdn_set_error("wgrad: nslabs < 1");
+    if (a->c0 && a->c1) return ssdn_set_error("wgrad: one input tensor per launch (c0 == 0 or c1 == 0)");
+    if (a->c0 && a->up0 && (a->ltw < 1 || a->lth < 1)) return ssdn_set_error("wgrad: upsampled input needs even tile origins (tile >= 2x2)");
     return 0;
+}
+// Row items per wave per tile and the kernel variant that fits them into the K-steps 0..ksteps-3 (prefetch distance 2):
+//   nl = 4, both = 0: one row item per K-step (input rows, then dZ rows), <= 4 loads per input row
+//   nl = 6, both = 1: one input row AND one dZ row per K-step, <= 6 loads per input row
+// nl = 99: the tile cannot be prefetched.
+struct WgItems { int rswx, rswd, nl, both; };
+static WgItems wgrad_items(const ssdn_wgrad_args* a, const WgGeom& g) {
+    WgItems t;
+    const int npix = g.TN * g.TH * g.TW;
+    const int ix = (g.HW * (a->Ktot / 8) + 63) / 64, id = (g.TW * (a->M / 8) + 63) / 64;
+    t.rswx = (g.TN * g.HH + WG_WAVES - 1) / WG_WAVES;
+    t.rswd = (g.TN * g.TH + WG_WAVES - 1) / WG_WAVES;
+    const int steps = (npix >> 4) - 2;             // loads are issued in K-steps 0..ksteps-3
+    const bool single = g.ntiles <= a->nslabs;     // one tile per workgroup: nothing to prefetch
+    t.nl = 99; t.both = 0;
+    if (id > WG_ND) return t;
+    if (ix <= 4 && (single || t.rswx + t.rswd <= steps)) { t.nl = 4; t.both = 0; }
+    else if (ix <= 6 && (single || (t.rswx <= steps && t.rswd <= steps))) { t.nl = 6; t.both = 1; }
+    return t;
 }
 int wgrad_lds_bytes(const ssdn_wgrad_args* a) {
     if (wgrad_validate(a)) return -1;
     WgGeom g = wg_geom(*a);
-    return g.NP * g.PSTR + (g.TN * g.TH * g.TW) * g.DSTR + 64;
+    if (wgrad_items(a, g).nl > 6) { ssdn_set_error("wgrad: the tile cannot be prefetched within its K-steps (too many rows / too wide rows)"); return -1; }
+    return 2 * (g.XB + g.DB) + 64;
 }
 
-template <int MT, int CPW>
+template <int MT, int CPW, int NL, bool BOTH, int PS, int KS, int RWX, int RWD>
 static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& x, hipStream_t s) {
-    size_t lds = (size_t)g.NP * g.PSTR + (size_t)(g.TN * g.TH * g.TW) * g.DSTR + 64;
+    size_t lds = 2 * ((size_t)g.XB + (size_t)g.DB) + 64;
     if (lds > 160 * 1024) return ssdn_set_error("wgrad: tiling needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
-        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad<MT, CPW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     double px = (double)a->N * a->H * a->W;
     prof_begin(SSDN_PROF_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad<MT, CPW>), dim3(a->nslabs), dim3(WG_THREADS), lds, s, *a, x);
+    hipLaunchKernelGGL((k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>), dim3(a->nslabs), dim3(WG_THREADS), lds, s, *a, x);
     prof_end(SSDN_PROF_WGRAD, s, 2.0 * px * a->M * a->Ktot * a->ntaps, px * 2.0 * (a->M + a->Ktot));
     return 0;
 }
@@ -283,19 +627,34 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     if (rc) return rc;
     WgGeom g = wg_geom(*a);
     WgAux x;
-    x.mg_hw = magic_ofw(g.HW);
+    x.trace = (unsigned long long*)ssdn_debug_get_trace();
     x.mg_hh = magic_ofw(g.HH);
     x.ccx = a->Ktot / 8;
     x.ccd = a->M / 8;
     x.mg_ccx = magic_ofw(x.ccx);
     x.mg_ccd = magic_ofw(x.ccd);
+    const WgItems wi = wgrad_items(a, g);
+    if (wi.nl > 6) return ssdn_set_error("wgrad: the tile cannot be prefetched within its K-steps (too many rows / too wide rows)");
+    x.rswx = wi.rswx; x.rswd = wi.rswd;
     const int MT = a->Mpad / 32;
     const int CT = a->ntaps * (a->Kpad / 32) + 1;
-    const int CPW = (CT + 7) / 8;
-#define WG_CASE(mt, cpw) if (MT == mt && CPW == cpw) rc = wgrad_launch<mt, cpw>(a, g, x, s); else
-    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4)
-    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4)
-    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4)
+    const int CPW = (CT + WG_WAVES - 1) / WG_WAVES;
+    // the hot shapes get the input pixel stride and the whole staging schedule as compile-time constants:
+    //   3x3, 48..96 input channels: stride 192 B, 16x8 tiles  -> 8 K-steps, 3 input + 2 dZ rows per wave
+    //   3x3, 16..32 input channels: stride  64 B, 16x16 tiles -> 16 K-steps, 5 + 4 rows per wave
+    const int ksteps = (g.TN * g.TH * g.TW) >> 4;
+    const bool st = !wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs;
+    const bool st8 = st && g.PSTR == 192 && ksteps == 8 && wi.rswx == 3 && wi.rswd == 2;
+    const bool st16 = st && g.PSTR == 64 && ksteps == 16 && wi.rswx == 5 && wi.rswd == 4;
+#define WG_CASE(mt, cpw) if (MT == mt && CPW == cpw) { \
+        if (wi.both) rc = wgrad_launch<mt, cpw, 6, true, 0, 0, 0, 0>(a, g, x, s); \
+        else if (st8 && mt >= 2 && (cpw == 5 || cpw == 7)) rc = wgrad_launch<mt, cpw, 4, false, 192, ((mt >= 2 && (cpw == 5 || cpw == 7)) ? 8 : 0), 3, 2>(a, g, x, s); \
+        else if (st16 && mt >= 2 && cpw == 3) rc = wgrad_launch<mt, cpw, 4, false, 64, ((mt >= 2 && cpw == 3) ? 16 : 0), 5, 4>(a, g, x, s); \
+        else rc = wgrad_launch<mt, cpw, 4, false, 0, 0, 0, 0>(a, g, x, s); \
+    } else
+    WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4) WG_CASE(1, 5) WG_CASE(1, 6) WG_CASE(1, 7)
+    WG_CASE(2, 1) WG_CASE(2, 2) WG_CASE(2, 3) WG_CASE(2, 4) WG_CASE(2, 5) WG_CASE(2, 6) WG_CASE(2, 7)
+    WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4) WG_CASE(3, 5) WG_CASE(3, 6) WG_CASE(3, 7)
     rc = ssdn_set_error("wgrad: unsupported shape MT=%d CPW=%d", MT, CPW);
 #undef WG_CASE
     if (rc) return rc;

@@ -168,20 +168,42 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
     return best[1]
 
 
-def choose_wgrad_tile(N, H, W, taps, Kpad, Mpad, budget=LDS_LIMIT):
+def _wg_stride(row_bytes):
+    """pixel stride of the weight-gradient kernel's LDS images: == 64 (mod 128) bytes (bank-conflict-free transpose reads)"""
+    return ((row_bytes + 63) & ~127) + 64
+
+
+def choose_wgrad_tile(N, H, W, taps, Kpad, Mpad, Ktot, M, cus, budget=LDS_LIMIT):
     padT, padB, padL, padR = _pads(taps)
     best = None
-    for ltw in range(0, min(5, _pow2ceil_log(W)) + 1):
+    for ltw in range(0, min(4, _pow2ceil_log(W)) + 1):
         for lth in range(0, min(8 - ltw, _pow2ceil_log(H)) + 1):
-            for ltn in range(max(0, 4 - ltw - lth), 8 - ltw - lth + 1):   # the kernel needs >= 16 pixels per tile
-                if ltn > max(_pow2ceil_log(N), 4 - ltw - lth):
+            for ltn in range(max(0, 5 - ltw - lth), 8 - ltw - lth + 1):   # the kernel needs >= 32 pixels per tile
+                if ltn > max(_pow2ceil_log(N), 5 - ltw - lth):
                     continue                                             # surplus images would only be masked lanes
                 TW, TH, TN = 1 << ltw, 1 << lth, 1 << ltn
                 tiles = -(-W // TW) * -(-H // TH) * -(-N // TN)
                 util = (N * H * W) / float(tiles * TN * TH * TW)
                 NP = TN * (TH + padT + padB) * (TW + padL + padR)
-                lds = NP * (Kpad * 2 + 16) + TN * TH * TW * (Mpad * 2 + 16) + 64
+                # two LDS images (the kernel prefetches tile i+1 while tile i is on the matrix cores) ...
+                HW_ = TW + padL + padR
+                # (each part of an image has one extra dummy row that absorbs void row items)
+                lds = 2 * ((NP + HW_) * _wg_stride(Kpad * 2) + (TN * TH * TW + TW) * _wg_stride(Mpad * 2)) + 64
                 if lds > budget:
+                    continue
+                # ... filled row by row: the rows of a tile are dealt to the kernel's 4 waves, a wave loads one row (<= 4
+                # 64-lane 16-byte loads for an input row, <= 3 for a dZ row) per 16-pixel K-step in all but the last two
+                # K-steps of a tile -- or, for wide rows (<= 6 loads), an input AND a dZ row per K-step.  Irrelevant when no
+                # workgroup gets a second tile.
+                HH, HW = TH + padT + padB, TW + padL + padR
+                ix, idz = -(-(HW * (Ktot // 8)) // 64), -(-(TW * (M // 8)) // 64)
+                rswx, rswd = -(-(TN * HH) // 4), -(-(TN * TH) // 4)
+                steps = TN * TH * TW // 16 - 2
+                single = tiles <= cus
+                if idz > 3:
+                    continue
+                if not ((ix <= 4 and (single or rswx + rswd <= steps)) or
+                        (ix <= 6 and (single or (rswx <= steps and rswd <= steps)))):
                     continue
                 key = (round(util, 3), TN * TH * TW, -NP, ltw)
                 if best is None or key > best[0]:
@@ -259,7 +281,7 @@ class NetPlan:
         if cblocks is not None:
             taps = [(0, 0)] * len(cblocks)
         Mpad = ceil_to(Mz, 32)
-        (ltw, lth, ltn), ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad)
+        (ltw, lth, ltn), ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad, Ktot, Mz, self.cus)
         nslabs = max(1, min(ntiles, self.cus))
         ntaps = len(taps)
         # every weight-gradient launch owns its slab: its reduction runs on another lane while the next launch is already
@@ -395,11 +417,9 @@ class NetPlan:
             self._wgrad(L[lb], View(g_tb), 96, View(ta), 96, 0, None, 0, 96, N, h, w, t3)
             g_ta = self.grad("g_" + tag + "a", N, h, w, 96)
             dgrad(lb, g_tb, 96, N, h, w, rt3, 96, View(g_ta), mask=View(ta))
-            if c_up + c_skip <= 96:
-                self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, View(skip), c_skip, c_up + c_skip_real, N, h, w, t3)
-            else:
-                self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, None, 0, c_up, N, h, w, t3, c_off=0, with_bias=True)
-                self._wgrad(L[la], View(g_ta), 96, None, 0, 0, View(skip), c_skip, c_skip_real, N, h, w, t3, c_off=c_up, with_bias=False)
+            # one input tensor per weight-gradient launch (the kernel's row loads have one base address)
+            self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, None, 0, c_up, N, h, w, t3, c_off=0, with_bias=True)
+            self._wgrad(L[la], View(g_ta), 96, None, 0, 0, View(skip), c_skip, c_skip_real, N, h, w, t3, c_off=c_up, with_bias=False)
             Mx = c_up + (c_skip if need_skip_grad else 0)
             dxs = self.grad("dxs_" + tag, N, h, w, Mx)
             dgrad(la, g_ta, 96, N, h, w, rt3, Mx, View(dxs))

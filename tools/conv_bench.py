@@ -64,6 +64,35 @@ def main():
 
 
 
+def all_ops(kind="wgrad"):
+    """time every op of one type of the training plan in isolation (us, TF/s)"""
+    B, P = 32, 64
+    cus = L.load().ssdn_device_cus()
+    plan = NetPlan("m/", 3, 9, True, B, P, P, cus=cus)
+    dev = torch.device("cuda:0")
+    flat = torch.randn(plan.nparams, device=dev) * 0.05
+    dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+    for name, t in dn.t.items():
+        if t.dtype in (torch.float16, torch.bfloat16):
+            t.copy_(torch.randn(t.shape, device=dev) * 0.5)
+    dn.pack.run(current_stream())
+    tot = 0.0
+    for op in plan.fwd + plan.bwd:
+        if op.type != kind:
+            continue
+        a = op.a
+        t = time_op(dn, op)
+        tot += t
+        if kind in ("wgrad", "conv"):
+            flops = 2.0 * a["N"] * a["H"] * a["W"] * a["M"] * a["Ktot"] * len(a["taps"])
+            print("%-18s %-5s N=%3d H=%3d K=%3d M=%3d taps=%d tile (%d,%d,%d) : %8.1f us  %7.1f TF" % (
+                a["layer"], a.get("role", kind), a["N"], a["H"], a["Ktot"], a["M"], len(a["taps"]), 1 << a["ltw"], 1 << a["lth"], 1 << a["ltn"],
+                t, flops / t / 1e6))
+        else:
+            print("%-18s %8.1f us" % (a.get("layer", ""), t))
+    print("total %.1f us" % tot)
+
+
 def trace(layer="decode_block_1.2", role="fwd"):
     """per-workgroup phase timeline from s_memtime stamps (ssdn_debug_set_trace)"""
     import ctypes as C
@@ -105,7 +134,9 @@ def trace(layer="decode_block_1.2", role="fwd"):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "trace":
+    if len(sys.argv) > 1 and sys.argv[1] == "all":
+        all_ops(*sys.argv[2:3])
+    elif len(sys.argv) > 1 and sys.argv[1] == "trace":
         trace(*(sys.argv[2:4]))
     else:
         main()
