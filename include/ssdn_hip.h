@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSDN_ABI_VERSION 1
+#define SSDN_ABI_VERSION 2
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -64,13 +64,15 @@ enum ssdn_op_type {
 };
 
 /* One record of the op list.  `args` points at the matching ssdn_*_args struct (host memory).
- * lane 0: the op is enqueued on the caller's stream.  lane k = 1, 2: on a library-owned side stream, AFTER everything that
- * precedes it in the list on lanes 0..k-1 (the executor inserts the hipEvent dependencies); a lane never waits for a higher
- * lane inside a list, but ssdn_run_ops joins all side streams back into the caller's stream before it returns.  The planner
- * guarantees the absence of WAR/WAW hazards between lanes: lane 1 carries the weight-gradient GEMMs of the backward pass
- * (they read tensors written once per step and write their OWN slab), lane 2 the slab reductions (they read that slab and
- * write the flat gradient, which nothing else touches) -- so the many small, latency-bound backward launches overlap instead
- * of queueing behind each other. */
+ * lane 0: the op is enqueued on the caller's stream.  Lanes 1..3 are library-owned side streams:
+ *   lanes 1 and 3 run an op AFTER everything that precedes it in the list on lane 0 (and on their own lane);
+ *   lane 2 runs an op AFTER everything that precedes it in the list on lanes 0, 1 and 3 (and on lane 2).
+ * The executor inserts the hipEvent dependencies; a lane never waits for a lane it does not depend on inside a list, but
+ * ssdn_run_ops joins all side streams back into the caller's stream before it returns.  The planner guarantees the absence
+ * of WAR/WAW hazards between lanes: lanes 1 and 3 carry (alternately) the weight-gradient GEMMs of the backward pass (they
+ * read tensors written once per step and write their OWN slab), lane 2 the slab reductions (they read that slab and write
+ * the flat gradient, which nothing else touches) -- so the many small, latency-bound backward launches overlap instead of
+ * queueing behind each other. */
 typedef struct ssdn_op {
     int32_t type;
     int32_t lane;
@@ -182,6 +184,10 @@ typedef struct ssdn_wgrad_args {
     float* bslab;
     int32_t nslabs;
     int32_t ltw, lth, ltn; /* pixel tile per iteration: 2^ltn x 2^lth x 2^ltw */
+    int32_t csplit;        /* 0: a workgroup owns every column tile of the output (grid = nslabs);
+                              1: a workgroup owns 4 column tiles (32 input channels of one tap, or the bias column):
+                                 grid = nslabs x ceil((ntaps*Kpad/32 + 1) / 4) -- for layers with few pixels, where
+                                 writing a full slab per workgroup would dominate */
 } ssdn_wgrad_args;
 
 /* ---- SSDN_OP_WREDUCE ------------------------------------------------------------------------
@@ -333,13 +339,17 @@ int ssdn_device_cus(void);
 /* In-stream profiler used by bench.py's roofline leg: when enabled for a kernel family, every launch of that family is
  * bracketed by a hipEvent pair ON THE LAUNCH STREAM; ssdn_profile_read() synchronises, returns the summed device time,
  * the number of launches and the ALGORITHMIC flops / bytes those launches stood for (DESIGN.md gives the formulas),
- * and resets the counters.  max_launches = 0 disables. */
+ * and resets the counters.  max_launches = 0 disables.  An event pair costs ~10 us of stream time (measured: it turns
+ * back-to-back kernels into kernels with gaps), so ssdn_profile_set_stride(kind, s) brackets only every s-th launch of the
+ * family: launches, flops, bytes and time then refer to the SAMPLED launches (a family's launch count per step is not a
+ * multiple of the stride bench.py uses, so the sample rotates over all layers). */
 #define SSDN_PROF_CONV_MT3 0
 #define SSDN_PROF_CONV_MT2 1
 #define SSDN_PROF_CONV_MT1 2
 #define SSDN_PROF_WGRAD 3
 #define SSDN_PROF_KINDS 4
 int ssdn_profile_enable(int kind, int max_launches);
+int ssdn_profile_set_stride(int kind, int stride);
 int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* flops, double* bytes);
 
 /* Hardware probes used by the test-suite (tests/test_hip_probe.py): raw lane mapping of

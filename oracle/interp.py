@@ -195,7 +195,7 @@ class Interp:
         self.store(dst, cpad, out)
 
     def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, coff, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn,
-                 slab=None, bslab=None):
+                 slab=None, bslab=None, csplit=0):
         x = _r16(self._gather(src0, src1, c0, c1, up0, N, H, W), self.fp16, "bf16")   # staged as bf16 on the device
         g = self.view(dz, M)
         self.slab = torch.zeros(len(taps), Mpad, Kpad)

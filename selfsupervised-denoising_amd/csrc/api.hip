@@ -22,17 +22,25 @@ struct ProfSlot {
     std::vector<hipEvent_t> ev;
     size_t used = 0;
     double flops = 0.0, bytes = 0.0;
+    long long seen = 0;      // launches of the family since enable
+    int stride = 1;          // every stride-th launch is bracketed (an event pair costs ~10 us of stream time)
+    bool armed = false;      // the launch in flight between prof_begin and prof_end is a sampled one
 };
 static ProfSlot g_prof[SSDN_PROF_KINDS];
 
 void prof_begin(int id, hipStream_t s) {
     ProfSlot& p = g_prof[id];
-    if (!p.on || p.used + 2 > p.ev.size()) return;
+    p.armed = false;
+    if (!p.on) return;
+    const bool pick = p.seen++ % p.stride == 0;
+    if (!pick || p.used + 2 > p.ev.size()) return;
+    p.armed = true;
     (void)hipEventRecord(p.ev[p.used], s);
 }
 void prof_end(int id, hipStream_t s, double flops, double bytes) {
     ProfSlot& p = g_prof[id];
-    if (!p.on || p.used + 2 > p.ev.size()) return;
+    if (!p.on || !p.armed) return;
+    p.armed = false;
     (void)hipEventRecord(p.ev[p.used + 1], s);
     p.used += 2;
     p.flops += flops;
@@ -89,11 +97,20 @@ int ssdn_profile_enable(int kind, int max_launches) {
     p.used = 0;
     p.flops = p.bytes = 0.0;
     p.on = max_launches > 0;
+    p.seen = 0;
+    p.armed = false;
     for (int i = 0; i < 2 * max_launches; ++i) {
         hipEvent_t e;
         if (hipEventCreate(&e) != hipSuccess) return ssdn_set_error("profile: hipEventCreate failed");
         p.ev.push_back(e);
     }
+    return 0;
+}
+
+int ssdn_profile_set_stride(int kind, int stride) {
+    if (kind < 0 || kind >= SSDN_PROF_KINDS) return ssdn_set_error("profile: bad kernel kind %d", kind);
+    if (stride < 1) return ssdn_set_error("profile: stride must be >= 1");
+    g_prof[kind].stride = stride;
     return 0;
 }
 
@@ -120,8 +137,8 @@ int ssdn_conv_lds_bytes(const ssdn_conv_args* a) { return conv_lds_bytes(a); }
 int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a) { return wgrad_lds_bytes(a); }
 
 #define SSDN_NEVENTS 256
-#define SSDN_NLANES 3
-static hipStream_t g_side[SSDN_NLANES] = {nullptr, nullptr, nullptr};   // [0] unused (= caller's stream)
+#define SSDN_NLANES 4
+static hipStream_t g_side[SSDN_NLANES] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused (= caller's stream)
 static hipEvent_t g_ev[SSDN_NEVENTS];
 static int g_ev_next = 0;
 static bool g_lanes_ready = false;
@@ -132,11 +149,14 @@ static int lanes_init() {
     g_lanes_ready = true;
     return 0;
 }
+// lanes a lane is ordered after (bit l = lane l): see ssdn_op in the header
+static const unsigned g_lane_deps[SSDN_NLANES] = {0u, 1u << 0, (1u << 0) | (1u << 1) | (1u << 3), 1u << 0};
 
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
-    hipStream_t lane_s[SSDN_NLANES] = {(hipStream_t)stream, nullptr, nullptr};
-    // dirty[l]: lane l has enqueued work that lane l+1 has not been ordered after yet
-    bool dirty[SSDN_NLANES] = {true, false, false}, used[SSDN_NLANES] = {true, false, false};
+    hipStream_t lane_s[SSDN_NLANES] = {(hipStream_t)stream, nullptr, nullptr, nullptr};
+    // dirty[s][d]: lane s has enqueued work that lane d (which depends on s) has not been ordered after yet
+    bool dirty[SSDN_NLANES][SSDN_NLANES] = {}, used[SSDN_NLANES] = {true, false, false, false};
+    for (int d = 1; d < SSDN_NLANES; ++d) dirty[0][d] = true;   // whatever the caller enqueued before this list
     static const bool one_lane = getenv("SSDN_ONE_LANE") != nullptr;   // tuning / debugging aid
     for (int i = 0; i < n; ++i) {
         const void* p = ops[i].args;
@@ -146,20 +166,16 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
         if (lane < 0 || lane >= SSDN_NLANES) return ssdn_set_error("op %d: bad lane %d", i, lane);
         if (lane > 0) {
             if (lanes_init()) return -1;
-            lane_s[1] = g_side[1];
-            lane_s[2] = g_side[2];
-            // lane k runs after everything that precedes it in the list on lanes 0..k-1: chain the pending orderings upwards
-            for (int l = 0; l < lane; ++l) {
-                if (dirty[l]) {
-                    hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
-                    SSDN_CHECK_HIP(hipEventRecord(e, lane_s[l]));
-                    SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[l + 1], e, 0));
-                    dirty[l] = false;
-                    if (l + 1 < lane) dirty[l + 1] = true;   // the wait itself must propagate to the next lane up
-                }
+            for (int l = 1; l < SSDN_NLANES; ++l) lane_s[l] = g_side[l];
+            for (int src = 0; src < SSDN_NLANES; ++src) {
+                if (!((g_lane_deps[lane] >> src) & 1) || !dirty[src][lane]) continue;
+                hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
+                SSDN_CHECK_HIP(hipEventRecord(e, lane_s[src]));
+                SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[lane], e, 0));
+                dirty[src][lane] = false;
             }
         }
-        dirty[lane] = true;
+        for (int d = 0; d < SSDN_NLANES; ++d) dirty[lane][d] = true;
         used[lane] = true;
         hipStream_t s = lane_s[lane];
         switch (ops[i].type) {

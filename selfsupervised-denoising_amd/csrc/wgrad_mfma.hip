@@ -116,6 +116,7 @@ struct WgAux {
 typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
 #define SSDN_BUFFER_RSRC_FLAGS 0x00020000   // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
 #define WG_ND 3                             // 64-lane loads per dZ row (<= 16 pixels x 12 chunks)
+#define WG_ONES_BYTES 4096                  // LDS area of bf16 1.0 behind the two images: B operand of the bias column
 
 // MFMA with the accumulator pinned to a register file.  A wave of this kernel owns up to 21 32x32 fp32 accumulators = 336
 // registers, more than the 256 AGPRs: the first 16 tiles live in AGPRs, the rest in VGPRs (the compiler will not split
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     bool ct_on[CPW], ct_bias[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-        int ct = wave + WG_WAVES * j;
+        int ct = blockIdx.y * (WG_WAVES * CPW) + wave + WG_WAVES * j;   // (gridDim.y > 1: csplit, CPW == 1)
         ct_on[j] = ct <= CT;
         ct_bias[j] = ct == CT;
         int tp = ct_on[j] && !ct_bias[j] ? ct / NTt : 0;
@@ -174,7 +175,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
 #pragma unroll
     for (int j = 0; j < CPW; ++j)
         stoff[j] = (a.dy[ct_tap[j]] * g.HW + a.dx[ct_tap[j]]) * g.PSTR + (a.coff[ct_tap[j]] + ct_nt[j] * 32) * 2;
-    const bool last_on = ct_on[CPW - 1], last_bias = ct_bias[CPW - 1];
+    const bool last_bias = ct_bias[CPW - 1];   // (an absent last column tile is computed like tap 0 and never written)
 
     // the input of one launch comes from ONE tensor (src0, optionally read through the 2x nearest upsampling, or src1)
     const bool use0 = a.c0 > 0;
@@ -214,6 +215,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     stamp();
     // ---- double-buffered pipeline over this workgroup's tiles -------------------------------------------------------
     const int bufsz = g.XB + g.DB;
+    {   // the bias column's B operand: an LDS area of bf16 1.0 (0x3f80) that its transpose reads are pointed at
+        u16x8 o;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) o[i] = 0x3f80;
+        *reinterpret_cast<u16x8*>(smem + 2 * bufsz + tid * 16) = o;
+    }
     const int ksteps = npix_tile >> 4;
     const int ntl = ((int)g.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
 
@@ -317,20 +324,15 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
 
-    half8 pvA[NPV], pvB[NPV];
-    int rlA = -1, rlB = -1, rdA = -1, rdB = -1;   // LDS row offsets of the items in flight (-1: none); rd*: dZ item
+    half8 pvA[NPV], pvB[NPV], pvC[KS > 0 ? NPV : 1];
+    int rlA = -1, rlB = -1, rdA = -1, rdB = -1, rlC = -1;   // LDS row offsets of the items in flight (-1: none); rd*: dZ item
 #pragma unroll
     for (int u = 0; u < NPV; ++u) pvA[u] = pvB[u] = zero_h8();
+    pvC[0] = zero_h8();
 
     // operand fragments: A (dZ, MT row tiles) double-buffered by K-step parity, B (input, CPW column tiles) refilled in place
     // right after the MFMAs that consumed it -- every LDS transpose read is issued one full K-step before its use.
     half8 afA[MT], afB[MT], bf[CPW];
-    {
-        u16x8 o;   // bf16 1.0 = 0x3f80 in every 16-bit slot: the B operand of the bias column
-#pragma unroll
-        for (int i = 0; i < 8; ++i) o[i] = 0x3f80;
-        bf[CPW - 1] = __builtin_bit_cast(half8, o);
-    }
     // per-lane part of the fragment addresses: the two pixels (of the 16 of a K-step) this lane supplies to the transpose
     // reads (r = 0,1 -> k elements 0..3 / 4..7); the K-step's first pixel adds a wave-uniform offset
     // (a K-step's 16 pixels are whole rows of one image, or whole images: tiles are <= 16 wide and all sizes powers of 2)
@@ -342,6 +344,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
         dlane[r] = e * g.DSTR + (i16 & 3) * 8;
         xlane[r] = ((tnl * g.HH + tyl) * g.HW + tx + g.padL) * g.PSTR + (i16 & 3) * 8;
     }
+
+    int xl_last[2];   // per-lane part of the last column tile's fragment address
+#pragma unroll
+    for (int r = 0; r < 2; ++r) xl_last[r] = last_bias ? lane * 8 : xlane[r] + mh * 32;
 
     for (int i = 0; i < ntl; ++i) {
         const char* xt_c = smem + (i & 1) * bufsz;
@@ -365,9 +371,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
             return xt_c + ((tn * g.HH + ty + g.padT) * g.HW) * g.PSTR;
         };
         auto read_b = [&](const char* xb, int j) __attribute__((always_inline)) -> half8 {
-            const char* p0 = (xb + stoff[j]) + (xlane[0] + mh * 32);
+            // (the bias column reads the area of ones instead: scalar select of the base, per-lane part chosen once)
+            const bool ones = j == CPW - 1 && last_bias;
+            const char* sb = ones ? smem + 2 * bufsz : xb + stoff[j];
+            const char* p0 = sb + (j == CPW - 1 ? xl_last[0] : xlane[0] + mh * 32);
             if constexpr (PS > 0) return cat8(tr16(p0), tr16(p0 + 4 * PS));
-            else return cat8(tr16(p0), tr16((xb + stoff[j]) + (xlane[1] + mh * 32)));
+            else return cat8(tr16(p0), tr16(sb + (j == CPW - 1 ? xl_last[1] : xlane[1] + mh * 32)));
         };
         auto mma = [&](auto Jc, auto Mc, const half8* afc) __attribute__((always_inline)) {
             constexpr int j = decltype(Jc)::value, mt = decltype(Mc)::value;
@@ -410,10 +419,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
             bool nisx = false;
             static_for<0, SLOTS>([&](auto Sc) __attribute__((always_inline)) {
                 constexpr int S = decltype(Sc)::value, j = S / MT, mt = S % MT;
-                if (j < CPW - 1 || last_on) mma(std::integral_constant<int, j>{}, std::integral_constant<int, mt>{}, afc);
+                mma(std::integral_constant<int, j>{}, std::integral_constant<int, mt>{}, afc);
                 if constexpr (S < MT) afn[S] = read_a1(ab, S);
                 if constexpr (mt == MT - 1) {
-                    if (j < CPW - 1 || !last_bias) bf[j] = read_b(xb, j);
+                    bf[j] = read_b(xb, j);
                 }
                 if constexpr (!BOTH) {
                     // side item w lives in slot MT + w * (SLOTS - MT) / NSIDE (all in the last slot when there are few slots)
@@ -465,7 +474,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
             for (int mt = 0; mt < MT; ++mt) afA[mt] = read_a1(ab, mt);
 #pragma unroll
             for (int j = 0; j < CPW; ++j)
-                if (j < CPW - 1 || !last_bias) bf[j] = read_b(xb, j);
+                bf[j] = read_b(xb, j);
         }
         if constexpr (KS > 0) {
             // ---- static schedule (hot shapes: one image per tile, KS K-steps, RWX input + RWD dZ rows per wave) -------------
@@ -477,11 +486,12 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
             static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(Kc)::value;
                 constexpr int LK = ks < RWX ? 1 : ks < RWX + RWD ? 2 : 0;                       // loaded in this K-step
-                constexpr int CK = ks < 2 ? 0 : ks - 2 < RWX ? 1 : ks - 2 < RWX + RWD ? 2 : 0;    // committed in this K-step
+                constexpr int CK = ks < 3 ? 0 : ks - 3 < RWX ? 1 : ks - 3 < RWX + RWD ? 2 : 0;    // committed in this K-step
+                static_assert(RWX + RWD + 3 <= KS, "row items must be committed within their tile");
                 half8* afc = (ks & 1) ? afB : afA;
                 half8* afn = (ks & 1) ? afA : afB;
-                half8* pv = (ks & 1) ? pvB : pvA;
-                int& ro = (ks & 1) ? rlB : rlA;          // LDS byte offset (inside an image) of the set's row
+                half8* pv = ks % 3 == 0 ? pvA : ks % 3 == 1 ? pvB : pvC;      // prefetch distance: 3 K-steps
+                int& ro = ks % 3 == 0 ? rlA : ks % 3 == 1 ? rlB : rlC;        // LDS byte offset (inside an image) of the set's row
                 constexpr int kn = (ks + 1) % KS;
                 const char* ab = abase(kn);
                 const char* xb = xbase(kn);
@@ -490,10 +500,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
                 constexpr int SLOTS = MT * CPW, NSIDE = 2 * NPV + 1;
                 static_for<0, SLOTS>([&](auto Sc) __attribute__((always_inline)) {
                     constexpr int S = decltype(Sc)::value, j = S / MT, mt = S % MT;
-                    if (j < CPW - 1 || last_on) mma(std::integral_constant<int, j>{}, std::integral_constant<int, mt>{}, afc);
+                    mma(std::integral_constant<int, j>{}, std::integral_constant<int, mt>{}, afc);
                     if constexpr (S < MT) afn[S] = read_a1(ab, S);
                     if constexpr (mt == MT - 1) {
-                        if (j < CPW - 1 || !last_bias) bf[j] = read_b(xb, j);
+                        bf[j] = read_b(xb, j);
                     }
                     static_for<0, NSIDE>([&](auto Wc) __attribute__((always_inline)) {
                         constexpr int w = decltype(Wc)::value;
@@ -577,6 +587,7 @@ static int wgrad_validate(const ssdn_wgrad_args* a) {
     if ((a->Mpad & 31) || a->Mpad > 96 || a->M > a->Mpad || (a->M & 7)) return ssdn_set_error("wgrad: Mpad must be 32/64/96, M %% 8 == 0");
     if (a->nslabs < 1) return ssdn_set_error("wgrad: nslabs < 1");
     if (a->c0 && a->c1) return ssdn_set_error("wgrad: one input tensor per launch (c0 == 0 or c1 == 0)");
+    if (a->csplit != 0 && a->csplit != 1) return ssdn_set_error("wgrad: csplit must be 0 or 1");
     if (a->c0 && a->up0 && (a->ltw < 1 || a->lth < 1)) return ssdn_set_error("wgrad: upsampled input needs even tile origins (tile >= 2x2)");
     return 0;
 }
@@ -603,12 +614,12 @@ int wgrad_lds_bytes(const ssdn_wgrad_args* a) {
     if (wgrad_validate(a)) return -1;
     WgGeom g = wg_geom(*a);
     if (wgrad_items(a, g).nl > 6) { ssdn_set_error("wgrad: the tile cannot be prefetched within its K-steps (too many rows / too wide rows)"); return -1; }
-    return 2 * (g.XB + g.DB) + 64;
+    return 2 * (g.XB + g.DB) + WG_ONES_BYTES;
 }
 
 template <int MT, int CPW, int NL, bool BOTH, int PS, int KS, int RWX, int RWD>
 static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& x, hipStream_t s) {
-    size_t lds = 2 * ((size_t)g.XB + (size_t)g.DB) + 64;
+    size_t lds = 2 * ((size_t)g.XB + (size_t)g.DB) + WG_ONES_BYTES;
     if (lds > 160 * 1024) return ssdn_set_error("wgrad: tiling needs %zu B of LDS (> 160 KiB)", lds);
     static bool attr_set = false;
     if (!attr_set) {
@@ -617,7 +628,8 @@ static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& 
     }
     double px = (double)a->N * a->H * a->W;
     prof_begin(SSDN_PROF_WGRAD, s);
-    hipLaunchKernelGGL((k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>), dim3(a->nslabs), dim3(WG_THREADS), lds, s, *a, x);
+    const int gy = a->csplit ? (a->ntaps * (a->Kpad / 32) + 1 + WG_WAVES - 1) / WG_WAVES : 1;
+    hipLaunchKernelGGL((k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>), dim3(a->nslabs, gy), dim3(WG_THREADS), lds, s, *a, x);
     prof_end(SSDN_PROF_WGRAD, s, 2.0 * px * a->M * a->Ktot * a->ntaps, px * 2.0 * (a->M + a->Ktot));
     return 0;
 }
@@ -638,7 +650,7 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     x.rswx = wi.rswx; x.rswd = wi.rswd;
     const int MT = a->Mpad / 32;
     const int CT = a->ntaps * (a->Kpad / 32) + 1;
-    const int CPW = (CT + WG_WAVES - 1) / WG_WAVES;
+    const int CPW = a->csplit ? 1 : (CT + WG_WAVES - 1) / WG_WAVES;
     // the hot shapes get the input pixel stride and the whole staging schedule as compile-time constants:
     //   3x3, 48..96 input channels: stride 192 B, 16x8 tiles  -> 8 K-steps, 3 input + 2 dZ rows per wave
     //   3x3, 16..32 input channels: stride  64 B, 16x16 tiles -> 16 K-steps, 5 + 4 rows per wave

@@ -4,6 +4,7 @@ into libssdn_hip.so per phase (forward / backward / optimiser).  No torch comput
 """
 from __future__ import annotations
 
+import os
 import ctypes as C
 import math
 from typing import Dict, List, Optional
@@ -21,15 +22,21 @@ def _ptr(t: torch.Tensor, byte_off: int = 0) -> int:
 class OpList:
     """A materialised op list: a ctypes array of ssdn_op plus the argument structs it points to."""
 
-    LANE = {"wgrad": 1, "wreduce": 2}    # weight-gradient GEMMs / slab reductions run on the library's side streams
+    # weight-gradient GEMMs / slab reductions run on the library's side streams.  (The executor also offers lane 3, a second
+    # weight-gradient lane; alternating the GEMMs between lanes 1 and 3 measured 4 % SLOWER: two of these kernels, each
+    # sized to own every CU, only thrash each other's LDS-resident pipelines.)
+    LANE = {"wgrad": (1,), "wreduce": (2,)}
 
     def __init__(self, recs, lanes: bool = False):
         self.args = [r[1] for r in recs]                      # keep the structs alive
         self.arr = (L.OpRec * max(1, len(recs)))()
+        count = {}
         for i, r in enumerate(recs):
             ty, a = r[0], r[1]
             self.arr[i].type = L.OP[ty]
-            self.arr[i].lane = self.LANE.get(ty, 0) if lanes else 0
+            choices = self.LANE.get(ty, (0,)) if lanes else (0,)
+            self.arr[i].lane = choices[count.get(ty, 0) % len(choices)]
+            count[ty] = count.get(ty, 0) + 1
             self.arr[i].args = C.cast(C.pointer(a), C.c_void_p)
         self.n = len(recs)
 
@@ -126,6 +133,7 @@ class DeviceNet:
             s.slab, s.bslab = _ptr(self.t[a["slab"]]), _ptr(self.t[a["bslab"]])
             s.nslabs = a["nslabs"]
             s.ltw, s.lth, s.ltn = a["ltw"], a["lth"], a["ltn"]
+            s.csplit = a.get("csplit", 0)
             if L.load().ssdn_wgrad_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("wgrad %s: %s" % (a["layer"], L.load().ssdn_last_error().decode()))
             return op.type, s

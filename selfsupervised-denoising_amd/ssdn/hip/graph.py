@@ -188,7 +188,7 @@ def choose_wgrad_tile(N, H, W, taps, Kpad, Mpad, Ktot, M, cus, budget=LDS_LIMIT)
                 # two LDS images (the kernel prefetches tile i+1 while tile i is on the matrix cores) ...
                 HW_ = TW + padL + padR
                 # (each part of an image has one extra dummy row that absorbs void row items)
-                lds = 2 * ((NP + HW_) * _wg_stride(Kpad * 2) + (TN * TH * TW + TW) * _wg_stride(Mpad * 2)) + 64
+                lds = 2 * ((NP + HW_) * _wg_stride(Kpad * 2) + (TN * TH * TW + TW) * _wg_stride(Mpad * 2)) + 4096
                 if lds > budget:
                     continue
                 # ... filled row by row: the rows of a tile are dealt to the kernel's 4 waves, a wave loads one row (<= 4
@@ -282,8 +282,21 @@ class NetPlan:
             taps = [(0, 0)] * len(cblocks)
         Mpad = ceil_to(Mz, 32)
         (ltw, lth, ltn), ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad, Ktot, Mz, self.cus)
-        nslabs = max(1, min(ntiles, self.cus))
         ntaps = len(taps)
+        # Split of the work over workgroups.  Every workgroup ends by writing its accumulators as one fp32 slab, at ~10 B
+        # per clock per CU -- for the full [ntaps][Mpad][Kpad] output that is ~33 K cycles, more than the matrix work of a
+        # layer with few pixels.  Such layers split the OUTPUT instead (csplit: 4 column tiles per workgroup, every
+        # workgroup staging all of its pixel tiles); cycle model measured on the device: a 16-pixel K-step costs ~1300
+        # cycles with all column tiles, ~750 (staging-bound) with 4.
+        ksteps = (1 << (ltw + lth + ltn)) // 16
+        slab_cyc = ntaps * Mpad * Kpad * 4 / 10.0
+        ns_full = max(1, min(ntiles, self.cus))
+        t_full = -(-ntiles // ns_full) * ksteps * 1300 + slab_cyc
+        gy = -(-(ntaps * Kpad // 32 + 1) // 4)
+        ns_split = max(1, min(ntiles, self.cus // gy))
+        t_split = -(-ntiles // ns_split) * ksteps * 750 + slab_cyc / gy
+        csplit = int(gy > 1 and t_split < 0.8 * t_full and not os.environ.get("SSDN_NO_CSPLIT"))
+        nslabs = ns_split if csplit else ns_full
         # every weight-gradient launch owns its slab: its reduction runs on another lane while the next launch is already
         # writing (1.2 GB in total for BASELINE config 2 -- 0.4 % of the 288 GB of HBM)
         self.nwgrad = getattr(self, "nwgrad", 0) + 1
@@ -292,7 +305,7 @@ class NetPlan:
         M_real = min(Mz, layer.M - m_off)
         self.bwd.append(Op("wgrad", dict(layer=layer.name, dz=dz, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                          taps=list(taps), coff=coff, M=Mz, Mpad=Mpad, Ktot=Ktot, Kpad=Kpad, nslabs=nslabs,
-                                         ltw=ltw, lth=lth, ltn=ltn, slab=slab, bslab=bslab)))
+                                         ltw=ltw, lth=lth, ltn=ltn, csplit=csplit, slab=slab, bslab=bslab)))
         self.bwd.append(Op("wreduce", dict(layer=layer.name, nslabs=nslabs, ntaps=ntaps, M=M_real, Mpad=Mpad, Kpad=Kpad,
                                            cin=cin_real, cin_full=layer.cin, m_off=m_off, c_off=c_off, with_bias=with_bias,
                                            tapblock=int(cblocks is not None), slab=slab, bslab=bslab)))

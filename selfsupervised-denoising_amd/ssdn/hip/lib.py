@@ -56,7 +56,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("dz", View), ("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32),
                 ("H", i32), ("W", i32), ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("coff", i32 * MAX_TAPS),
                 ("M", i32), ("Mpad", i32), ("Ktot", i32), ("Kpad", i32), ("slab", vp), ("bslab", vp), ("nslabs", i32), ("ltw", i32),
-                ("lth", i32), ("ltn", i32)]
+                ("lth", i32), ("ltn", i32), ("csplit", i32)]
 
 
 class WreduceArgs(C.Structure):
@@ -116,7 +116,7 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
 # every symbol include/ssdn_hip.h declares
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
-           "ssdn_profile_read"]
+           "ssdn_profile_read", "ssdn_profile_set_stride"]
 PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3)
 
 _lib = None
@@ -150,11 +150,13 @@ def load() -> C.CDLL:
     lib.ssdn_probe_tr16.restype = C.c_int
     lib.ssdn_profile_enable.argtypes = [C.c_int, C.c_int]
     lib.ssdn_profile_enable.restype = C.c_int
+    lib.ssdn_profile_set_stride.argtypes = [C.c_int, C.c_int]
+    lib.ssdn_profile_set_stride.restype = C.c_int
     lib.ssdn_profile_read.argtypes = [C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double), C.POINTER(C.c_double)]
     lib.ssdn_profile_read.restype = C.c_int
     lib.ssdn_struct_size.argtypes = [C.c_int]
     lib.ssdn_struct_size.restype = C.c_int
-    if lib.ssdn_abi_version() != 1:
+    if lib.ssdn_abi_version() != 2:
         raise SsdnHipError("libssdn_hip.so ABI version mismatch")
     _lib = lib
     return lib

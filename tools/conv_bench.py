@@ -93,6 +93,26 @@ def all_ops(kind="wgrad"):
     print("total %.1f us" % tot)
 
 
+def pair(*layers):
+    """run the forward convs of the given layers back to back (launch-gap experiments under rocprofv3)"""
+    B, P = 32, 64
+    cus = L.load().ssdn_device_cus()
+    plan = NetPlan("m/", 3, 9, True, B, P, P, cus=cus)
+    dev = torch.device("cuda:0")
+    flat = torch.randn(plan.nparams, device=dev) * 0.05
+    dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+    dn.pack.run(current_stream())
+    recs = []
+    for name in layers:
+        for op in plan.fwd:
+            if op.type == "conv" and op.a["layer"] == name:
+                recs.append(dn._mat(op))
+    ol = OpList(recs)
+    for _ in range(30):
+        ol.run(current_stream())
+    torch.cuda.synchronize()
+
+
 def trace(layer="decode_block_1.2", role="fwd"):
     """per-workgroup phase timeline from s_memtime stamps (ssdn_debug_set_trace)"""
     import ctypes as C
@@ -134,7 +154,9 @@ def trace(layer="decode_block_1.2", role="fwd"):
 
 
 if __name__ == "__main__":
-    if len(sys.argv) > 1 and sys.argv[1] == "all":
+    if len(sys.argv) > 1 and sys.argv[1] == "pair":
+        pair(*sys.argv[2:])
+    elif len(sys.argv) > 1 and sys.argv[1] == "all":
         all_ops(*sys.argv[2:3])
     elif len(sys.argv) > 1 and sys.argv[1] == "trace":
         trace(*(sys.argv[2:4]))
