@@ -188,7 +188,16 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_UNROT_BWD: rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_WGRAD: rc = launch_wgrad((const ssdn_wgrad_args*)p, s); break;
             case SSDN_OP_WREDUCE: rc = launch_wreduce((const ssdn_wreduce_args*)p, s); break;
-            case SSDN_OP_WPACK: rc = launch_wpack((const ssdn_wpack_args*)p, s); break;
+            case SSDN_OP_WPACK: {   // a run of consecutive re-packs on the same lane is one launch
+                const ssdn_wpack_args* items[WPACK_MULTI_MAX];
+                int m = 0;
+                while (m < WPACK_MULTI_MAX && i + m < n && ops[i + m].type == SSDN_OP_WPACK && ops[i + m].args &&
+                       (one_lane ? 0 : ops[i + m].lane) == lane)
+                    items[m] = (const ssdn_wpack_args*)ops[i + m].args, ++m;
+                rc = m > 1 ? launch_wpack_multi(items, m, s) : launch_wpack((const ssdn_wpack_args*)p, s);
+                i += m - 1;
+                break;
+            }
             case SSDN_OP_GRAD_PACK: rc = launch_grad_pack((const ssdn_grad_pack_args*)p, s); break;
             case SSDN_OP_HEAD_SSDN: rc = launch_head((const ssdn_head_args*)p, s); break;
             case SSDN_OP_HEAD_FINAL: rc = launch_head_final((const ssdn_head_final_args*)p, s); break;

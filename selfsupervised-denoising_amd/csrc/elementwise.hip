@@ -291,8 +291,7 @@ static __device__ __forceinline__ int k_to_cin(int k, int c0, int c1_real) {
     int r = k - c0;
     return r < c1_real ? c0 + r : -1;
 }
-__global__ void k_wpack(ssdn_wpack_args a) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+static __device__ __forceinline__ void wpack_element(const ssdn_wpack_args& a, long long idx) {
     long long nf = (long long)a.ntaps * a.Mpad_f * a.Ktot;
     long long nd = a.wd ? (long long)a.ntaps * a.Mpad_d * a.Kd : 0;
     if (idx < nf) {
@@ -312,9 +311,39 @@ __global__ void k_wpack(ssdn_wpack_args a) {
         ((unsigned short*)a.wd)[e] = f2bf(v);   // data-gradient shadow is bf16 (gradients are bf16)
     }
 }
+static inline long long wpack_count(const ssdn_wpack_args* a) {
+    return (long long)a->ntaps * a->Mpad_f * a->Ktot + (a->wd ? (long long)a->ntaps * a->Mpad_d * a->Kd : 0);
+}
+__global__ void k_wpack(ssdn_wpack_args a) { wpack_element(a, (long long)blockIdx.x * blockDim.x + threadIdx.x); }
 int launch_wpack(const ssdn_wpack_args* a, hipStream_t s) {
-    long long n = (long long)a->ntaps * a->Mpad_f * a->Ktot + (a->wd ? (long long)a->ntaps * a->Mpad_d * a->Kd : 0);
-    hipLaunchKernelGGL(k_wpack, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    hipLaunchKernelGGL(k_wpack, dim3(ew_grid(wpack_count(a))), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}
+// Every layer's shadows in ONE launch: the executor merges runs of consecutive SSDN_OP_WPACK ops (after an optimiser step
+// all ~20 layers are re-packed; 20 launches of ~4 us each were 2.5 % of a training step).  The per-layer descriptors travel
+// in the kernel argument segment; a block serves one layer.
+struct WpackTable {
+    ssdn_wpack_args e[WPACK_MULTI_MAX];
+    int bstart[WPACK_MULTI_MAX + 1];   // first block of each entry
+    int n;
+};
+__global__ void k_wpack_multi(WpackTable t) {
+    int i = 0;
+    while (i + 1 < t.n && (int)blockIdx.x >= t.bstart[i + 1]) ++i;
+    wpack_element(t.e[i], (long long)(blockIdx.x - t.bstart[i]) * blockDim.x + threadIdx.x);
+}
+int launch_wpack_multi(const ssdn_wpack_args* const* items, int n, hipStream_t s) {
+    if (n < 1 || n > WPACK_MULTI_MAX) return ssdn_set_error("wpack: bad batch size %d", n);
+    WpackTable t;
+    t.n = n;
+    int b = 0;
+    for (int i = 0; i < n; ++i) {
+        t.e[i] = *items[i];
+        t.bstart[i] = b;
+        b += ew_grid(wpack_count(items[i]));
+    }
+    t.bstart[n] = b;
+    if (b > 0) hipLaunchKernelGGL(k_wpack_multi, dim3(b), dim3(EW_BLOCK), 0, s, t);
     return 0;
 }
 

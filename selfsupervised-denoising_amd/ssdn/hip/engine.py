@@ -25,7 +25,9 @@ class OpList:
     # weight-gradient GEMMs / slab reductions run on the library's side streams.  (The executor also offers lane 3, a second
     # weight-gradient lane; alternating the GEMMs between lanes 1 and 3 measured 4 % SLOWER: two of these kernels, each
     # sized to own every CU, only thrash each other's LDS-resident pipelines.)
-    LANE = {"wgrad": (1,), "wreduce": (2,)}
+    # The slab reduction follows its GEMM on the same lane: every cross-lane dependency is a hipEventRecord on the producing
+    # stream, which costs that stream ~5-10 us of bubble -- a separate reduction lane (2) measured 4.5 % slower.
+    LANE = {"wgrad": (1,), "wreduce": (1,)}
 
     def __init__(self, recs, lanes: bool = False):
         self.args = [r[1] for r in recs]                      # keep the structs alive
@@ -66,8 +68,31 @@ class DeviceNet:
             # zero-initialised once: padding channels / never-written slab corners must be finite
             self.t[name] = torch.zeros(spec.shape, dtype=self.DT[spec.kind], device=device)
         self.fwd = OpList([self._mat(op) for op in plan.fwd])
-        self.bwd = OpList([self._mat(op) for op in plan.bwd], lanes=True)
+        self.bwd = OpList(self._batch_side_ops([self._mat(op) for op in plan.bwd]), lanes=True)
         self.pack = OpList([self._mat(op) for op in plan.pack])
+
+    @staticmethod
+    def _batch_side_ops(recs, every: Optional[int] = None):
+        """Re-order the backward list so that the side-lane ops (weight-gradient GEMMs + slab reductions) are issued in
+        batches, after every `every`-th main-lane convolution instead of right after the op that produced their input.
+        Delaying a side-lane op is always legal (it only reads tensors that are written once per step); each lane switch
+        costs the main stream an event record, so fewer switches = fewer bubbles."""
+        if every is None:
+            every = int(os.environ.get("SSDN_SIDE_BATCH", "1"))
+        if every <= 1:
+            return recs
+        out, pending, nconv = [], [], 0
+        for r in recs:
+            if r[0] in OpList.LANE:
+                pending.append(r)
+                continue
+            out.append(r)
+            if r[0] == "conv":
+                nconv += 1
+                if nconv % every == 0:
+                    out += pending
+                    pending = []
+        return out + pending
 
     # ---- helpers ------------------------------------------------------------------------------------------
     def tensor(self, short: str) -> torch.Tensor:
