@@ -39,6 +39,25 @@ static __device__ __forceinline__ unsigned short f2bf(float f) {
     return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
 }
 static __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+// packed 16-bit pairs in one dword: round-to-nearest-even hardware conversions (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)
+typedef __attribute__((__vector_size__(2 * sizeof(unsigned)))) unsigned u32x2_t;
+typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
+typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2_t;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2_t;
+typedef __attribute__((__vector_size__(2 * sizeof(_Float16)))) _Float16 f16x2_t;
+static __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+    f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
+}
+static __device__ __forceinline__ unsigned pack_f16x2(float lo, float hi) {
+    f32x2_t f = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f, f16x2_t));
+}
+static __device__ __forceinline__ float bf_lo(unsigned w) { return __uint_as_float(w << 16); }
+static __device__ __forceinline__ float bf_hi(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+static __device__ __forceinline__ float f16_lo(unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w)[0]; }
+static __device__ __forceinline__ float f16_hi(unsigned w) { return (float)__builtin_bit_cast(f16x2_t, w)[1]; }
+#define SSDN_BUFFER_RSRC_FLAGS 0x00020000   // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
 static __device__ __forceinline__ u16x8 ld_b8(const unsigned short* p) { return *reinterpret_cast<const u16x8*>(p); }
 static __device__ __forceinline__ void st_b8(unsigned short* p, u16x8 v) { *reinterpret_cast<u16x8*>(p) = v; }
 static __device__ __forceinline__ u16x4 ld_b4(const unsigned short* p) { return *reinterpret_cast<const u16x4*>(p); }

@@ -308,11 +308,30 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     // (measured on the 96-channel full-resolution layers: 60-75 us of a 190 us launch were the fragmented stores).
     constexpr int OSTR = MT * 64 + 16;
     char* ot = smem;
+    // ---- LDS -> HBM goes one image ROW of the tile at a time ------------------------------------------------------------
+    // A row of the tile is TW pixels x cpp 16-byte pieces; its position (image, y), validity and base addresses are
+    // wave-uniform and live on the scalar unit as buffer resources whose num_records is the part of the row inside the image,
+    // so the hardware drops the stores (and zero-fills the mask / skip-gradient loads) of pixels past the right edge; per lane
+    // only (pixel, piece) -> two byte offsets remain.  (The per-piece index arithmetic of the flat version was ~40 VALU
+    // instructions per 16 bytes and, with the mask and skip-gradient handled in scalar bf16 emulation, made the epilogue of
+    // the data-gradient role 38 K of its 84 K cycles per tile.)
+    int m_cnt = a.M - x.m_base;
+    m_cnt = m_cnt > WROWS ? WROWS : m_cnt;
+    const int cpp = m_cnt >> 3;                       // 16-byte pieces per pixel
+    const unsigned mg = magic_dev(cpp);
+    const int rowp = g.TW * cpp;                      // pieces per row
+    const int ipr = (rowp + 63) >> 6;                 // 64-lane instructions per row
+    const int nrows = g.TN * g.TH;
+    constexpr int NWAVES = CONV_THREADS / 64;
+    const int items = ((nrows + NWAVES - 1) / NWAVES) * ipr;   // (row, instruction) items of this wave
+    const bool has_mask = a.mask.p != nullptr, has_add = a.add.p != nullptr;
     // bias of this launch's channels, staged once in LDS behind the output tile (a per-lane global gather of 4*12 floats
     // showed up as ~30 us on the 96-channel layers)
     float* bl = reinterpret_cast<float*>(smem + (size_t)npix * OSTR);
     if (tid < WROWS) bl[tid] = (a.bias && x.m_base + tid < a.M) ? a.bias[x.m_base + tid] : 0.f;
     __syncthreads();
+    // 16-bit NHWC output: the tile is transposed through LDS (the input tile is dead after the last barrier) so that HBM sees
+    // whole 16-byte-per-lane, pixel-contiguous stores instead of 8-byte fragments of every cache line
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int q = wave * 64 + nt * 32 + l31;
@@ -329,82 +348,78 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
                     v[j] = acc[mt][nt][gq * 4 + j] + bb[j];
                     if (a.act) v[j] = lrelu(v[j]);
                 }
-                if constexpr (BF) {
-                    u16x4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = f2bf(v[j]);
-                    *reinterpret_cast<u16x4*>(ot + q * OSTR + ml * 2) = o;
-                } else {
-                    half4 o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) o[j] = (h16)v[j];
-                    *reinterpret_cast<half4*>(ot + q * OSTR + ml * 2) = o;
-                }
+                // packed round-to-nearest-even conversions (v_cvt_pk_f16_f32 / v_cvt_pk_bf16_f32)
+                u32x2_t o;
+                o[0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
+                o[1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
+                *reinterpret_cast<u32x2_t*>(ot + q * OSTR + ml * 2) = o;
             }
         }
     }
     __syncthreads();
     stamp();
     if (x.ablate & 8) return;
-    int m_cnt = a.M - x.m_base;
-    m_cnt = m_cnt > WROWS ? WROWS : m_cnt;
-    const int cpp = m_cnt >> 3;                       // 16-byte chunks per pixel
-    const unsigned mg = magic_dev(cpp);
-    // 4 output pieces per thread per round: their mask / skip-gradient loads are all issued before any is consumed
-    // (one dependent global round trip per piece made the data-gradient epilogue 50 us slower than the forward one)
+    // items in flight: the mask / skip-gradient loads of a batch are all issued before any is consumed.  (Measured: batches of
+    // 6 or 12, or issuing the first batch before the accumulators are converted, are slower than batches of 4.)
     constexpr int EB = 4;
-    for (int e0 = tid; e0 < npix * cpp; e0 += EB * CONV_THREADS) {
+    for (int it0 = 0; it0 < items; it0 += EB) {
         half8 mk[EB], ad[EB];
-        long long pixs[EB];
-        int qs[EB], cs[EB];
-        bool ok[EB];
+        __amdgpu_buffer_rsrc_t rd[EB];
+        int lo[EB], go[EB];
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
-            const int e = e0 + u * CONV_THREADS;
-            const int q = mg ? __umulhi((unsigned)e, mg) : e;
-            const int c = e - q * cpp;
-            const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
-            const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
-            ok[u] = e < npix * cpp && n < a.N && y < a.H && xx < a.W;
-            qs[u] = q; cs[u] = c;
-            pixs[u] = ((long long)n * a.H + y) * a.W + xx;
+            const int it = it0 + u;
+            const int rs = it / ipr, ii = it - rs * ipr;            // scalar
+            const int row = wave + NWAVES * rs;
+            const int tn = row >> a.lth, ty = row & (g.TH - 1);
+            const int n = n0 + tn, y = y0 + ty;
+            const bool ok = it < items && row < nrows && n < a.N && y < a.H && x0 < a.W;
+            const long long pix0 = ((long long)n * a.H + y) * a.W + x0;
+            const int wpx = a.W - x0 < g.TW ? a.W - x0 : g.TW;      // pixels of the row inside the image
+            const int j = lane + 64 * ii;
+            const int px = mg ? __umulhi((unsigned)j, mg) : j, c = j - px * cpp;
+            const bool on = j < rowp;
+            lo[u] = ((row << a.ltw) + px) * OSTR + c * 16;
+            go[u] = on ? (px * a.dst.cs + c * 8) * 2 : (int)0x80000000;
+            rd[u] = __builtin_amdgcn_make_buffer_rsrc((void*)((h16*)a.dst.p + pix0 * a.dst.cs + a.dst.co + x.m_base), 0,
+                                                      ok ? ((wpx - 1) * a.dst.cs + m_cnt) * 2 : 0, SSDN_BUFFER_RSRC_FLAGS);
             mk[u] = zero_h8(); ad[u] = zero_h8();
-            if (ok[u]) {
-                const int m = x.m_base + c * 8;
-                if (a.mask.p) mk[u] = ld_h8((const h16*)a.mask.p + pixs[u] * a.mask.cs + a.mask.co + m);
-                if (a.add.p) ad[u] = ld_h8((const h16*)a.add.p + pixs[u] * a.add.cs + a.add.co + m);   // raw 16-bit words
+            if (has_mask) {
+                __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)((const h16*)a.mask.p + pix0 * a.mask.cs + a.mask.co + x.m_base), 0, ok ? ((wpx - 1) * a.mask.cs + m_cnt) * 2 : 0,
+                    SSDN_BUFFER_RSRC_FLAGS);
+                mk[u] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rm, on ? (px * a.mask.cs + c * 8) * 2 : (int)0x80000000, 0, 0));
+            }
+            if (has_add) {
+                __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                    (void*)((const h16*)a.add.p + pix0 * a.add.cs + a.add.co + x.m_base), 0, ok ? ((wpx - 1) * a.add.cs + m_cnt) * 2 : 0,
+                    SSDN_BUFFER_RSRC_FLAGS);
+                ad[u] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(ra, on ? (px * a.add.cs + c * 8) * 2 : (int)0x80000000, 0, 0));
             }
         }
 #pragma unroll
         for (int u = 0; u < EB; ++u) {
-            if (!ok[u]) continue;
-            const int m = x.m_base + cs[u] * 8;
-            half8 o = *reinterpret_cast<const half8*>(ot + qs[u] * OSTR + cs[u] * 16);
-            if (a.add.p || a.mask.p) {
-                float v[8];
-                if constexpr (BF) {
-                    const u16x8 ob = __builtin_bit_cast(u16x8, o), ab = __builtin_bit_cast(u16x8, ad[u]);
+            u32x4_t o = *reinterpret_cast<const u32x4_t*>(ot + lo[u]);      // 8 outputs as 4 packed pairs (fp16 or bf16)
+            if (has_add || has_mask) {
+                const u32x4_t ab = __builtin_bit_cast(u32x4_t, ad[u]), mb = __builtin_bit_cast(u32x4_t, mk[u]);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = bf2f(ob[j]) + (a.add.p ? bf2f(ab[j]) : 0.f);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = (float)o[j] + (a.add.p ? (float)ad[u][j] : 0.f);
-                }
-                if (a.mask.p) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] *= lrelu_grad((float)mk[u][j]);
-                }
-                if constexpr (BF) {
-                    u16x8 ob;
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) ob[j] = f2bf(v[j]);
-                    o = __builtin_bit_cast(half8, ob);
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) o[j] = (h16)v[j];
+                for (int w = 0; w < 4; ++w) {
+                    float v0, v1;
+                    if constexpr (BF) {
+                        v0 = bf_lo(o[w]) + (has_add ? bf_lo(ab[w]) : 0.f);
+                        v1 = bf_hi(o[w]) + (has_add ? bf_hi(ab[w]) : 0.f);
+                    } else {
+                        v0 = f16_lo(o[w]) + (has_add ? f16_lo(ab[w]) : 0.f);
+                        v1 = f16_hi(o[w]) + (has_add ? f16_hi(ab[w]) : 0.f);
+                    }
+                    if (has_mask) {   // LeakyReLU'(pre-activation sign): the mask is the fp16 activation, slope where it is <= 0
+                        v0 *= lrelu_grad(f16_lo(mb[w]));
+                        v1 *= lrelu_grad(f16_hi(mb[w]));
+                    }
+                    o[w] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
                 }
             }
-            st_h8((h16*)a.dst.p + pixs[u] * a.dst.cs + a.dst.co + m, o);      // raw 16-bit words (fp16 or bf16)
+            __builtin_amdgcn_raw_buffer_store_b128(o, rd[u], go[u], 0, 0);
         }
     }
     stamp();

@@ -81,8 +81,6 @@ static __host__ __device__ inline WgGeom wg_geom(const ssdn_wgrad_args& a) {
 static __device__ __forceinline__ unsigned fdivw(unsigned x, unsigned magic) {
     return __umulhi(x, magic) + (x & (unsigned)-(int)(magic == 0));
 }
-typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2_t;
-typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2_t;
 // 8 fp16 -> 8 bf16 (v_cvt_f32_f16 x2 + v_cvt_pk_bf16_f32 per pair, round-to-nearest-even)
 static __device__ __forceinline__ half8 cvt_h8_to_bf8(half8 v) {
     unsigned w[4];
@@ -91,12 +89,10 @@ static __device__ __forceinline__ half8 cvt_h8_to_bf8(half8 v) {
         f32x2_t f = {(float)v[2 * i], (float)v[2 * i + 1]};
         w[i] = __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2_t));
     }
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
     u32x4_t r = {w[0], w[1], w[2], w[3]};
     return __builtin_bit_cast(half8, r);
 }
 static __device__ __forceinline__ half8 mask_h8(half8 v, bool keep) {
-    typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
     u32x4_t r = __builtin_bit_cast(u32x4_t, v);
     const unsigned m = (unsigned)-(int)keep;
     r[0] &= m; r[1] &= m; r[2] &= m; r[3] &= m;
@@ -113,8 +109,6 @@ struct WgAux {
     int rswx, rswd;           // rows of the input halo image / of the dZ image each wave stages per tile
 };
 
-typedef __attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned u32x4_t;
-#define SSDN_BUFFER_RSRC_FLAGS 0x00020000   // raw buffer, 32-bit data format (gfx90a / gfx94x / gfx950)
 #define WG_ND 3                             // 64-lane loads per dZ row (<= 16 pixels x 12 chunks)
 #define WG_ONES_BYTES 4096                  // LDS area of bf16 1.0 behind the two images: B operand of the bias column
 
