@@ -34,9 +34,7 @@ static __device__ __forceinline__ void st_h4(h16* p, half4 v) { *reinterpret_cas
 
 // ---- bf16 (gradient tensors): stored as raw 16-bit words; round-to-nearest-even from fp32, NaN kept quiet ----
 static __device__ __forceinline__ unsigned short f2bf(float f) {
-    unsigned u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
-    return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    return __builtin_bit_cast(unsigned short, (__bf16)f);   // v_cvt_pk_bf16_f32: round-to-nearest-even, NaN stays NaN
 }
 static __device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
 // packed 16-bit pairs in one dword: round-to-nearest-even hardware conversions (v_cvt_pk_bf16_f32 / v_cvt_pk_f16_f32)

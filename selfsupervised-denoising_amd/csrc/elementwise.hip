@@ -12,13 +12,13 @@ static inline int ew_grid(long long n) {
 // PACK_INPUT: rotate-stack, NCHW f32 -> NHWC f16   (noise_network.py:187-189, utils/data.py:42-67)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pack_input(ssdn_pack_input_args a) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // (launchers reject > 2^31 elements: 32-bit index math)
     const int H = a.H, W = a.W;
     long long total = (long long)a.R * a.B * H * W;
     if (idx >= total) return;
     int j = idx % W;
     int i = (idx / W) % H;
-    int nb = idx / ((long long)W * H);
+    int nb = idx / (unsigned)(W * H);
     int r = nb / a.B, b = nb % a.B;
     int sy, sx;  // source coordinates in the un-rotated image
     switch (r) {
@@ -27,7 +27,7 @@ __global__ void k_pack_input(ssdn_pack_input_args a) {
         case 2: sy = H - 1 - i; sx = W - 1 - j; break;  // rotate(x,180)[i,j] = x[H-1-i, W-1-j]
         default: sy = H - 1 - j; sx = i; break;         // rotate(x,270)[i,j] = x[H-1-j, i]
     }
-    h16* d = (h16*)a.dst.p + idx * a.dst.cs + a.dst.co;
+    h16* d = (h16*)a.dst.p + (long long)idx * a.dst.cs + a.dst.co;
     for (int c0 = 0; c0 < a.cpad; c0 += 8) {
         half8 v = zero_h8();
 #pragma unroll
@@ -39,6 +39,7 @@ __global__ void k_pack_input(ssdn_pack_input_args a) {
 int launch_pack_input(const ssdn_pack_input_args* a, hipStream_t s) {
     if (a->R == 4 && a->H != a->W) return ssdn_set_error("pack_input: blind-spot rotation needs square images");
     long long n = (long long)a->R * a->B * a->H * a->W;
+    if (n >= (1ll << 31)) return ssdn_set_error("pack_input: too many elements for 32-bit indexing");
     hipLaunchKernelGGL(k_pack_input, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
@@ -47,15 +48,15 @@ int launch_pack_input(const ssdn_pack_input_args* a, hipStream_t s) {
 // POOL_FWD / POOL_BWD  (noise_network.py:64-67; models/utility.py:37-53)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_pool_fwd(ssdn_pool_args a) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // (launchers reject > 2^31 elements: 32-bit index math)
     const int C8 = a.C >> 3, Ho = a.H >> 1, Wo = a.W >> 1;
     long long total = (long long)a.N * Ho * Wo * C8;
     if (idx >= total) return;
     int c = (idx % C8) * 8;
-    long long p = idx / C8;
+    const unsigned p = idx / C8;
     int j = p % Wo;
     int i = (p / Wo) % Ho;
-    int n = p / ((long long)Wo * Ho);
+    int n = p / (unsigned)(Wo * Ho);
     const h16* src = (const h16*)a.act.p + a.act.co + c;
     int r0 = a.shifted ? 2 * i - 1 : 2 * i;
     float m[8];
@@ -80,20 +81,21 @@ __global__ void k_pool_fwd(ssdn_pool_args a) {
 int launch_pool_fwd(const ssdn_pool_args* a, hipStream_t s) {
     if ((a->C & 7) || (a->H & 1) || (a->W & 1)) return ssdn_set_error("pool: C%%8, H%%2, W%%2 must be 0");
     long long n = (long long)a->N * (a->H / 2) * (a->W / 2) * (a->C / 8);
+    if (n >= (1ll << 31)) return ssdn_set_error("k_pool_fwd: too many elements for 32-bit indexing");
     hipLaunchKernelGGL(k_pool_fwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
 
 __global__ void k_pool_bwd(ssdn_pool_args a) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // (launchers reject > 2^31 elements: 32-bit index math)
     const int C8 = a.C >> 3, Ho = a.H >> 1, Wo = a.W >> 1;
     long long total = (long long)a.N * Ho * Wo * C8;
     if (idx >= total) return;
     int c = (idx % C8) * 8;
-    long long p = idx / C8;
+    const unsigned p = idx / C8;
     int j = p % Wo;
     int i = (p / Wo) % Ho;
-    int n = p / ((long long)Wo * Ho);
+    int n = p / (unsigned)(Wo * Ho);
     const h16* act = (const h16*)a.act.p + a.act.co + c;
     unsigned short* dz = (unsigned short*)a.dz.p + a.dz.co + c;                     // gradients are bf16
     u16x8 g = ld_b8((const unsigned short*)a.dpool.p + a.dpool.co + c + (((long long)n * Ho + i) * Wo + j) * a.dpool.cs);
@@ -143,6 +145,7 @@ __global__ void k_pool_bwd(ssdn_pool_args a) {
 int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s) {
     if ((a->C & 7) || (a->H & 1) || (a->W & 1)) return ssdn_set_error("pool: C%%8, H%%2, W%%2 must be 0");
     long long n = (long long)a->N * (a->H / 2) * (a->W / 2) * (a->C / 8);
+    if (n >= (1ll << 31)) return ssdn_set_error("k_pool_bwd: too many elements for 32-bit indexing");
     hipLaunchKernelGGL(k_pool_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
@@ -151,15 +154,15 @@ int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s) {
 // UPSUM_BWD: adjoint of nearest 2x upsample (+ LeakyReLU' of the producer)   (noise_network.py:102,110,120)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_upsum_bwd(ssdn_upsum_args a) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // (launchers reject > 2^31 elements: 32-bit index math)
     const int C8 = a.C >> 3;
     long long total = (long long)a.N * a.H * a.W * C8;
     if (idx >= total) return;
     int c = (idx % C8) * 8;
-    long long p = idx / C8;
+    const unsigned p = idx / C8;
     int j = p % a.W;
     int i = (p / a.W) % a.H;
-    int n = p / ((long long)a.W * a.H);
+    int n = p / (unsigned)(a.W * a.H);
     const unsigned short* src = (const unsigned short*)a.src.p + a.src.co + c;   // bf16 gradient
     float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
@@ -168,15 +171,16 @@ __global__ void k_upsum_bwd(ssdn_upsum_args a) {
 #pragma unroll
         for (int q = 0; q < 8; ++q) acc[q] += bf2f(v[q]);
     }
-    half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + p * a.mask.cs);
+    half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + (long long)p * a.mask.cs);
     u16x8 o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) o[q] = f2bf(acc[q] * lrelu_grad((float)mk[q]));
-    st_b8((unsigned short*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
+    st_b8((unsigned short*)a.dst.p + a.dst.co + c + (long long)p * a.dst.cs, o);
 }
 int launch_upsum_bwd(const ssdn_upsum_args* a, hipStream_t s) {
     if (a->C & 7) return ssdn_set_error("upsum: C%%8 must be 0");
     long long n = (long long)a->N * a->H * a->W * (a->C / 8);
+    if (n >= (1ll << 31)) return ssdn_set_error("k_upsum_bwd: too many elements for 32-bit indexing");
     hipLaunchKernelGGL(k_upsum_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
@@ -187,17 +191,17 @@ int launch_upsum_bwd(const ssdn_upsum_args* a, hipStream_t s) {
 //   r=0: (u,v)=(i,j); r=1 (rot 270): (P-1-j, i); r=2 (rot 180): (P-1-i, P-1-j); r=3 (rot 90): (j, P-1-i)
 // ------------------------------------------------------------------------------------------------
 __global__ void k_unrot_fwd(ssdn_unrot_args a) {
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // (launchers reject > 2^31 elements: 32-bit index math)
     const int P = a.P, C8 = a.C >> 3;
     long long total = (long long)a.B * P * P * 4 * C8;
     if (idx >= total) return;
     int c = (idx % C8) * 8;
-    long long t = idx / C8;
+    const unsigned t = idx / C8;
     int r = t & 3;
-    long long p = t >> 2;
+    const unsigned p = t >> 2;
     int j = p % P;
     int i = (p / P) % P;
-    int b = p / ((long long)P * P);
+    int b = p / (unsigned)(P * P);
     int u, v;
     switch (r) {
         case 0: u = i; v = j; break;
@@ -208,26 +212,27 @@ __global__ void k_unrot_fwd(ssdn_unrot_args a) {
     half8 val = zero_h8();
     if (u >= 1)
         val = ld_h8((const h16*)a.src.p + a.src.co + c + ((((long long)r * a.B + b) * P + (u - 1)) * P + v) * a.src.cs);
-    st_h8((h16*)a.dst.p + a.dst.co + r * a.C + c + p * a.dst.cs, val);
+    st_h8((h16*)a.dst.p + a.dst.co + r * a.C + c + (long long)p * a.dst.cs, val);
 }
 int launch_unrot_fwd(const ssdn_unrot_args* a, hipStream_t s) {
     if (a->C & 7) return ssdn_set_error("unrot: C%%8 must be 0");
     long long n = (long long)a->B * a->P * a->P * 4 * (a->C / 8);
+    if (n >= (1ll << 31)) return ssdn_set_error("k_unrot_fwd: too many elements for 32-bit indexing");
     hipLaunchKernelGGL(k_unrot_fwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
 
 __global__ void k_unrot_bwd(ssdn_unrot_args a) {
     // dY[rB+b, y, x, c] = (y+1 < P ? dU[b, i, j, r*C + c] : 0) * lrelu'(Y),  (u,v) = (y+1, x) -> (i,j) inverse map
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // (launchers reject > 2^31 elements: 32-bit index math)
     const int P = a.P, C8 = a.C >> 3;
     long long total = (long long)4 * a.B * P * P * C8;
     if (idx >= total) return;
     int c = (idx % C8) * 8;
-    long long p = idx / C8;
+    const unsigned p = idx / C8;
     int x = p % P;
     int y = (p / P) % P;
-    int nb = p / ((long long)P * P);
+    int nb = p / (unsigned)(P * P);
     int r = nb / a.B, b = nb % a.B;
     u16x8 o = zero_b8();
     int u = y + 1, v = x;
@@ -240,15 +245,16 @@ __global__ void k_unrot_bwd(ssdn_unrot_args a) {
             default: i = P - 1 - v; j = u; break;         // u = j, v = P-1-i
         }
         u16x8 g = ld_b8((const unsigned short*)a.src.p + a.src.co + r * a.C + c + (((long long)b * P + i) * P + j) * a.src.cs);
-        half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + p * a.mask.cs);
+        half8 mk = ld_h8((const h16*)a.mask.p + a.mask.co + c + (long long)p * a.mask.cs);
 #pragma unroll
         for (int q = 0; q < 8; ++q) o[q] = f2bf(bf2f(g[q]) * lrelu_grad((float)mk[q]));
     }
-    st_b8((unsigned short*)a.dst.p + a.dst.co + c + p * a.dst.cs, o);
+    st_b8((unsigned short*)a.dst.p + a.dst.co + c + (long long)p * a.dst.cs, o);
 }
 int launch_unrot_bwd(const ssdn_unrot_args* a, hipStream_t s) {
     if (a->C & 7) return ssdn_set_error("unrot: C%%8 must be 0");
     long long n = (long long)4 * a->B * a->P * a->P * (a->C / 8);
+    if (n >= (1ll << 31)) return ssdn_set_error("k_unrot_bwd: too many elements for 32-bit indexing");
     hipLaunchKernelGGL(k_unrot_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
@@ -258,17 +264,17 @@ int launch_unrot_bwd(const ssdn_unrot_args* a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 __global__ void k_grad_pack(ssdn_grad_pack_args a) {
     // gradients travel as bf16 (fp32 exponent range): no loss scale is needed, scale_out is written as {1, 1}
-    long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    long long HW = (long long)a.H * a.W;
-    long long total = a.N * HW;
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;   // (launchers reject > 2^31 elements: 32-bit index math)
+    const unsigned HW = a.H * a.W;
+    long long total = (long long)a.N * HW;
     if (idx == 0 && a.scale_out) {
         a.scale_out[0] = 1.f;
         a.scale_out[1] = 1.f;
     }
     if (idx >= total) return;
     int n = idx / HW;
-    long long pix = idx % HW;
-    unsigned short* d = (unsigned short*)a.dst.p + a.dst.co + idx * a.dst.cs;
+    const unsigned pix = idx % HW;
+    unsigned short* d = (unsigned short*)a.dst.p + a.dst.co + (long long)idx * a.dst.cs;
     for (int c0 = 0; c0 < a.cpad; c0 += 8) {
         u16x8 v = zero_b8();
 #pragma unroll
@@ -279,6 +285,7 @@ __global__ void k_grad_pack(ssdn_grad_pack_args a) {
 }
 int launch_grad_pack(const ssdn_grad_pack_args* a, hipStream_t s) {
     long long n = (long long)a->N * a->H * a->W;
+    if (n >= (1ll << 31)) return ssdn_set_error("k_grad_pack: too many elements for 32-bit indexing");
     hipLaunchKernelGGL(k_grad_pack, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
