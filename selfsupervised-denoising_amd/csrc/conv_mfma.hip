@@ -58,6 +58,7 @@ struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
     unsigned mg_ntaps;      // magic reciprocal of ntaps
     int m_base;             // first output channel of this launch (multiple of 32)
+    int nblk;               // blocks of MT*32 output channels in this launch (consecutive workgroups share a pixel tile)
     int ablate;             // tuning aid (env SSDN_CONV_ABLATE): 1 no MFMA, 2 no tile staging, 4 no weight stream, 8 no stores
     unsigned long long* trace;   // tuning aid (ssdn_debug_set_trace): 32 s_memtime stamps per workgroup, or NULL
     int desync;             // first-round workgroups start (hash(block) & 7) * desync * 8128 cycles late (0 = off)
@@ -90,13 +91,16 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     constexpr int WBUF = WROWS * STR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, KC);
+    // blockIdx.x % nblk: block of MT*32 output channels (the 384-channel 1x1 layers are 4 such blocks; as ONE launch the
+    // four workgroups that share a pixel tile are dispatched back to back and share its input through L2)
+    x.m_base += (int)(blockIdx.x % (unsigned)x.nblk) * (MT * 32);
     char* tile = smem;
     char* wl0 = smem + (size_t)g.NP * STR;
     char* wl1 = wl0 + WBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
+    int bid = blockIdx.x / (unsigned)x.nblk;
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
     const int n0 = bid * g.TN, y0 = ty_i * g.TH, x0 = tx_i * g.TW;
@@ -146,7 +150,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     half8 wrA[NW], wrB[NW], wrC[NW];    // three register sets: the weight stream runs THREE steps ahead of the MFMA work
     // every workgroup walks the taps in a different rotation: all workgroups of a launch stream the SAME 166 KB of weights,
     // and in lock-step they would all hit the same few L2 channels with the same 9 KB slice at the same moment
-    const int rot = (x.ablate & 64) ? 0 : (int)(blockIdx.x % (unsigned)a.ntaps);
+    const int rot = (x.ablate & 64) ? 0 : (int)((blockIdx.x / (unsigned)x.nblk) % (unsigned)a.ntaps);
     auto tap_of = [&](int tseq) { int t = tseq + rot; return t >= a.ntaps ? t - a.ntaps : t; };
     auto w_issue = [&](half8 (&wr)[NW], int step) {
         step = step < nsteps ? step : nsteps - 1;      // past the end: re-load the last slice (never committed)
@@ -467,19 +471,16 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
         attr_set = true;
     }
     int grid = g.tiles_x * g.tiles_y * g.groups_n;
-    for (int by = 0; by < nblk_y; ++by) {
-        ConvAux xx = x;
-        xx.m_base = x.m_base + by * MT * 32;
-        // algorithmic work of THIS launch: real output channels x input channel slots x taps x real pixels
-        int m_real = a->M - xx.m_base;
-        m_real = m_real < 0 ? 0 : (m_real > MT * 32 ? MT * 32 : m_real);
-        double px = (double)a->N * a->H * a->W;
-        double flops = 2.0 * px * m_real * a->Ktot * a->ntaps;
-        double bytes = px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
-        prof_begin(3 - MT, s);
-        hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid), dim3(CONV_THREADS), lds, s, *a, xx);
-        prof_end(3 - MT, s, flops, bytes);
-    }
+    // algorithmic work of THIS launch: real output channels x input channel slots x taps x real pixels
+    int m_real = a->M - x.m_base;
+    m_real = m_real < 0 ? 0 : (m_real > nblk_y * MT * 32 ? nblk_y * MT * 32 : m_real);
+    double px = (double)a->N * a->H * a->W;
+    double flops = 2.0 * px * m_real * a->Ktot * a->ntaps;
+    double bytes = nblk_y * px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
+    prof_begin(3 - MT, s);
+    x.nblk = nblk_y;
+    hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid * nblk_y), dim3(CONV_THREADS), lds, s, *a, x);
+    prof_end(3 - MT, s, flops, bytes);
     return 0;
 }
 

@@ -1,0 +1,25 @@
+#!/bin/bash
+# Collect the round's profile evidence on the GPU box (run through gpurun); outputs under gpurun_out/final/.
+set -u
+export TMPDIR=/tmp
+R=$GRAFT_REPO_ROOT
+OUT=$R/gpurun_out/final
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+# 1. un-profiled bench line (the number the other files are compared with)
+timeout 300 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/bench_line.json 2> $OUT/bench_line.err
+# 2. kernel trace + stats of the bench command
+timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/kt.log 2>&1
+cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
+python $R/tools/timeline.py $(find $OUT/kt -name "*kernel_trace.csv" | head -1) 10 > $OUT/bench_timeline.txt 2>&1
+# 3. HBM-side traffic (separate passes)
+bash $R/tools/pmc_traffic.sh > $OUT/traffic.txt 2>&1
+# 4. SQ counters of the two MFMA kernels on the full-resolution 96->96 3x3 layer
+bash $R/tools/pmc_wgrad.sh decode_block_1.2 fwd > $OUT/pmc_conv_fwd.txt 2>&1
+bash $R/tools/pmc_wgrad.sh decode_block_1.2 dgrad > $OUT/pmc_conv_dgrad.txt 2>&1
+bash $R/tools/pmc_wgrad.sh decode_block_1.2 wgrad > $OUT/pmc_wgrad.txt 2>&1
+# 5. per-launch timings in isolation
+timeout 200 python $R/tools/conv_bench.py all wgrad > $OUT/wgrad_isolated.txt 2>&1
+timeout 200 python $R/tools/conv_bench.py all conv > $OUT/conv_isolated.txt 2>&1
+rm -rf $OUT/kt/*/*.db 2>/dev/null
+ls -la $OUT
