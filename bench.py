@@ -146,6 +146,14 @@ def main():
     if rank == 0:
         value = args.steps * B * world / dt
         achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
+        # HBM-side traffic of the same kernel family: PMC passes cannot run inside this process, so the per-launch figure is
+        # the committed result of tools/pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE); null if absent
+        traffic = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "r01_final_traffic.json")) as f:
+                traffic = int(json.load(f)["hbm_bytes_per_launch"])
+        except (OSError, KeyError, ValueError):
+            pass
         res = {
             "metric": "training patches/sec (64x64 gauss25 SSDN)", "value": round(value, 2), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
@@ -156,7 +164,9 @@ def main():
                        "achieved_train_tflops_algorithmic": round(value * TRAIN_GFLOP_PER_PATCH / 1e3, 2)},
             "roofline": {"bound": "mfma", "kernel": "k_conv<3> (implicit-GEMM conv, fwd + dgrad roles, 96-wide output tiles)",
                          "achieved": round(achieved, 2), "peak": MFMA_FP16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                         "traffic_unit": "HBM-side bytes per launch (rocprofv3 FETCH_SIZE*2 + WRITE_SIZE, profiles/r01_final_traffic.json)",
+                         "algorithmic_bytes_per_launch": int(by.value / max(1, cnt.value)),
                          "launches": int(cnt.value), "sampling": "every %dth launch of the timed region" % PROF_STRIDE, "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 3),
                          "kernel_time_share": round(PROF_STRIDE * ms.value / 1e3 / dt, 4)},
         }
