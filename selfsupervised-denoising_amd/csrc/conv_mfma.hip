@@ -49,6 +49,15 @@ static __host__ __device__ inline ConvGeom conv_geom(int ltw, int lth, int ltn, 
     return g;
 }
 
+// 1-tap (1x1) layers with several channel chunks use the asynchronous tile pipeline (see k_conv): two unpadded LDS tile
+// buffers, chunk c+1 fetched with buffer_load ... lds while chunk c is on the matrix cores.  Needs every chunk to come from
+// one plain (not upsampled) source tensor.
+static __host__ __device__ inline bool conv_async(const ssdn_conv_args& a, int kc) {
+    if (a.ntaps != 1 || a.Ktot / kc < 2 || a.dy[0] != 0 || a.dx[0] != 0) return false;
+    if (a.c0 > 0 && a.up0) return false;
+    return a.c1 == 0 || a.c0 == 0 || a.c0 % kc == 0;
+}
+
 // exact x / d for x*d < 2^32 via a 32-bit magic reciprocal; magic == 0 encodes d == 1 (its reciprocal does not fit)
 static __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
 static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
@@ -93,14 +102,26 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     const ConvGeom g = conv_geom(a.ltw, a.lth, a.ltn, a.ntaps, a.dy, a.dx, a.N, a.H, a.W, KC);
     // blockIdx.x % nblk: block of MT*32 output channels (the 384-channel 1x1 layers are 4 such blocks; as ONE launch the
     // four workgroups that share a pixel tile are dispatched back to back and share its input through L2)
-    x.m_base += (int)(blockIdx.x % (unsigned)x.nblk) * (MT * 32);
+    // Workgroups are dealt to the 8 XCDs round-robin by id and each XCD has its own L2: the nblk workgroups of one pixel
+    // tile get ids 8 apart (id = 8 * (nblk * (tile / 8) + block) + tile % 8), i.e. the SAME XCD, back to back.
+    const unsigned wg_j = blockIdx.x >> 3, wg_xcd = blockIdx.x & 7;
+    const unsigned wg_tile = x.nblk > 1 ? (wg_j / (unsigned)x.nblk) * 8 + wg_xcd : blockIdx.x;
+    x.m_base += (x.nblk > 1 ? (int)(wg_j % (unsigned)x.nblk) : 0) * (MT * 32);
+    if (wg_tile >= (unsigned)(g.tiles_x * g.tiles_y * g.groups_n)) return;   // (grid is rounded up to a multiple of 8 tiles)
+    // ASYNC (1x1 layers, >= 2 channel chunks): the tile of chunk c+1 is fetched by the LDS-DMA path (buffer_load ... lds:
+    // no registers, no ds_write, asynchronous) into the second of two UNPADDED tile buffers while chunk c is on the matrix
+    // cores -- a 1x1 layer re-stages its tile for every 18 MFMAs per wave, and with synchronous staging that latency was
+    // most of its time.  (LDS-DMA writes 64 consecutive 16-byte pieces per wave instruction, hence the unpadded layout.)
+    const bool ASYNC = conv_async(a, KC) && !(x.ablate & 128);
+    const int tstr = ASYNC ? KC * 2 : STR;                 // LDS stride of a tile pixel
+    const int tbytes = g.NP * tstr;
     char* tile = smem;
-    char* wl0 = smem + (size_t)g.NP * STR;
+    char* wl0 = smem + (size_t)(ASYNC ? 2 : 1) * tbytes;
     char* wl1 = wl0 + WBUF;
 
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x / (unsigned)x.nblk;
+    int bid = wg_tile;
     const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
     const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
     const int n0 = bid * g.TN, y0 = ty_i * g.TH, x0 = tx_i * g.TW;
@@ -113,7 +134,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         int q = wave * 64 + nt * 32 + l31;
         int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
         if (tn >= g.TN) tn = ty = tx = 0;   // tile smaller than the workgroup: surplus lanes compute on pixel 0, store nothing
-        bbase[nt] = ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * STR + kh * 16;
+        bbase[nt] = ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * tstr + kh * 16;
     }
     const int abase = l31 * STR + kh * 16;
 
@@ -150,7 +171,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     half8 wrA[NW], wrB[NW], wrC[NW];    // three register sets: the weight stream runs THREE steps ahead of the MFMA work
     // every workgroup walks the taps in a different rotation: all workgroups of a launch stream the SAME 166 KB of weights,
     // and in lock-step they would all hit the same few L2 channels with the same 9 KB slice at the same moment
-    const int rot = (x.ablate & 64) ? 0 : (int)((blockIdx.x / (unsigned)x.nblk) % (unsigned)a.ntaps);
+    const int rot = (x.ablate & 64) ? 0 : (int)(wg_tile % (unsigned)a.ntaps);
     auto tap_of = [&](int tseq) { int t = tseq + rot; return t >= a.ntaps ? t - a.ntaps : t; };
     auto w_issue = [&](half8 (&wr)[NW], int step) {
         step = step < nsteps ? step : nsteps - 1;      // past the end: re-load the last slice (never committed)
@@ -194,18 +215,42 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int f = f0 + u * CONV_THREADS;
-                if (f < nflat) *reinterpret_cast<half8*>(tile + (f / CC8) * STR + (f % CC8) * 16) = v[u];
+                if (f < nflat) *reinterpret_cast<half8*>(tile + (f / CC8) * tstr + (f % CC8) * 16) = v[u];
             }
         }
     };
+
+    // ---- ASYNC: LDS-DMA fetch of channel chunk `ch` into tile buffer `buf` (no halo: ntaps == 1) ------------------------
+    // flat piece f = tid + 256 u  ->  (pixel f / CC8, 16-byte piece f % CC8); lane i of a wave instruction lands at
+    // M0 + 16 i, i.e. at piece (wave*64 + 256 u + i) of the unpadded tile.  Out-of-image pixels get an offset beyond
+    // num_records: the hardware writes zeros.
+    auto async_issue = [&](int ch, int buf) __attribute__((always_inline)) {
+        const int k0 = ch * KC;
+        const bool from0 = k0 < a.c0;
+        const unsigned long long bp = (unsigned long long)((const h16*)(from0 ? a.src0.p : a.src1.p) + (from0 ? a.src0.co + k0 : a.src1.co + k0 - a.c0));
+        const int scs = from0 ? a.src0.cs : a.src1.cs;
+        const u32x4_t rs = {(unsigned)bp, (unsigned)(bp >> 32) & 0xffffu, (unsigned)(((long long)a.N * a.H * a.W - 1) * scs + KC) * 2u, SSDN_BUFFER_RSRC_FLAGS};
+        for (int f0 = 0; f0 < nflat; f0 += CONV_THREADS) {
+            const int f = f0 + tid;
+            const int q = f / CC8, cc = f % CC8;
+            const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
+            const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
+            const bool ok = f < nflat && n < a.N && y < a.H && xx < a.W;
+            const int voff = ok ? (((n * a.H + y) * a.W + xx) * scs + cc * 8) * 2 : (int)0x80000000;
+            const unsigned ldsbase = (unsigned)(size_t)(tile + buf * tbytes) + (unsigned)(f0 + wave * 64) * 16u;
+            asm volatile("s_mov_b32 m0, %0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" :: "s"(ldsbase), "v"(voff), "s"(rs) : "memory");
+        }
+    };
+    auto async_wait = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
 
     // ---- one pipeline step on the matrix cores: KS K-steps, fully unrolled, ping-pong fragments, immediate offsets ----
     auto compute = [&](const char* wl, int step) {
         if (x.ablate & 1) return;
         const int ch = fdiv(step, x.mg_ntaps), t = tap_of(step - ch * a.ntaps);
-        const int toff = (a.dy[t] * g.HW + a.dx[t]) * STR;
-        const char* b0p = tile + bbase[0] + toff;
-        const char* b1p = tile + bbase[1] + toff;
+        const int toff = (a.dy[t] * g.HW + a.dx[t]) * tstr;
+        const char* tcur = tile + (ASYNC ? (step & 1) * tbytes : 0);
+        const char* b0p = tcur + bbase[0] + toff;
+        const char* b1p = tcur + bbase[1] + toff;
         const char* ap = wl + abase;
         half8 bq[2][2], aq[2][MT];
         bq[0][0] = *reinterpret_cast<const half8*>(b0p);
@@ -233,13 +278,15 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     auto advance = [&](half8 (&wr_next)[NW], char* buf_next, int step) {
         if (step + 1 < nsteps) {
             const int ch = fdiv(step, x.mg_ntaps), nch = fdiv(step + 1, x.mg_ntaps);
-            if (nch != ch) {
+            if (nch != ch && !ASYNC) {
                 __syncthreads();
                 stage_tile(nch);
             }
             w_commit(wr_next, buf_next);
         }
+        if (ASYNC) async_wait();          // the tile of step+1 has landed (every wave waits for its own loads, then the barrier)
         if (!(x.ablate & 32)) __syncthreads();
+        if (ASYNC && step + 2 < nsteps) async_issue(step + 2, step & 1);   // the buffer of `step` is free now
         stamp();
     };
 
@@ -253,6 +300,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     w_issue(wrA, 0);
     w_issue(wrB, 1);
     w_issue(wrC, 2);
+    if (ASYNC) async_issue(1, 1);
     stage_tile(0);
     w_commit(wrA, wl0);
     __syncthreads();
@@ -448,7 +496,7 @@ static int conv_validate(const ssdn_conv_args* a) {
 }
 
 static size_t conv_lds(const ssdn_conv_args* a, const ConvGeom& g, int mt) {
-    size_t main_b = (size_t)g.NP * g.PSTR + 2 * (size_t)mt * 32 * g.WSTR;
+    size_t main_b = (conv_async(*a, a->kc) ? 2 * (size_t)g.NP * a->kc * 2 : (size_t)g.NP * g.PSTR) + 2 * (size_t)mt * 32 * g.WSTR;
     size_t epi_b = a->dst32 ? 0 : (size_t)(g.TN * g.TH * g.TW) * (mt * 64 + 16) + mt * 32 * 4;
     return main_b > epi_b ? main_b : epi_b;
 }
@@ -479,7 +527,8 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     double bytes = nblk_y * px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
     prof_begin(3 - MT, s);
     x.nblk = nblk_y;
-    hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid * nblk_y), dim3(CONV_THREADS), lds, s, *a, x);
+    const int grid_all = nblk_y > 1 ? ((grid + 7) / 8) * 8 * nblk_y : grid;
+    hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid_all), dim3(CONV_THREADS), lds, s, *a, x);
     prof_end(3 - MT, s, flops, bytes);
     return 0;
 }

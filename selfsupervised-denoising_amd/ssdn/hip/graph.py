@@ -153,6 +153,8 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
                 NP = TN * (TH + padT + padB) * (TW + padL + padR)
                 for kc in kcs:
                     lds = NP * (kc * 2 + 16) + 2 * mt * 32 * (kc * 2 + 16)
+                    if len(taps) == 1 and Ktot // kc >= 2:   # 1x1 layers may run the two-buffer asynchronous tile pipeline
+                        lds = max(lds, 2 * NP * kc * 2 + 2 * mt * 32 * (kc * 2 + 16))
                     if out16:      # the output tile is transposed through the same LDS in the epilogue
                         lds = max(lds, TN * TH * TW * (mt * 64 + 16) + mt * 128)
                     if lds > budget:
