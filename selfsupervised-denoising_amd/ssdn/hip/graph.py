@@ -283,22 +283,33 @@ class NetPlan:
         if cblocks is not None:
             taps = [(0, 0)] * len(cblocks)
         Mpad = ceil_to(Mz, 32)
-        (ltw, lth, ltn), ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad, Ktot, Mz, self.cus)
         ntaps = len(taps)
         # Split of the work over workgroups.  Every workgroup ends by writing its accumulators as one fp32 slab, at ~10 B
         # per clock per CU -- for the full [ntaps][Mpad][Kpad] output that is ~33 K cycles, more than the matrix work of a
         # layer with few pixels.  Such layers split the OUTPUT instead (csplit: 4 column tiles per workgroup, every
         # workgroup staging all of its pixel tiles); cycle model measured on the device: a 16-pixel K-step costs ~1300
-        # cycles with all column tiles, ~750 (staging-bound) with 4.
-        ksteps = (1 << (ltw + lth + ltn)) // 16
+        # cycles with all column tiles, ~750 (staging-bound) with 4.  (The tile is chosen for the number of workgroups that
+        # share the pixels: a workgroup with several tiles needs a tile it can prefetch.)
         slab_cyc = ntaps * Mpad * Kpad * 4 / 10.0
-        ns_full = max(1, min(ntiles, self.cus))
-        t_full = -(-ntiles // ns_full) * ksteps * 1300 + slab_cyc
         gy = -(-(ntaps * Kpad // 32 + 1) // 4)
-        ns_split = max(1, min(ntiles, self.cus // gy))
-        t_split = -(-ntiles // ns_split) * ksteps * 750 + slab_cyc / gy
-        csplit = int(gy > 1 and t_split < 0.8 * t_full and not os.environ.get("SSDN_NO_CSPLIT"))
-        nslabs = ns_split if csplit else ns_full
+
+        def candidate(groups, kstep_cyc, slab_share):
+            cus_eff = max(1, self.cus // groups)
+            tile, ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad, Ktot, Mz, cus_eff)
+            ns = max(1, min(ntiles, cus_eff))
+            ksteps = (1 << sum(tile)) // 16
+            return -(-ntiles // ns) * ksteps * kstep_cyc + slab_cyc * slab_share, tile, ns
+
+        t_full, tile_f, ns_full = candidate(1, 1300, 1.0)
+        csplit = 0
+        (ltw, lth, ltn), nslabs = tile_f, ns_full
+        if gy > 1 and not os.environ.get("SSDN_NO_CSPLIT"):
+            try:
+                t_split, tile_s, ns_split = candidate(gy, 750, 1.0 / gy)
+            except ValueError:          # no tile the fewer, fatter workgroups could prefetch
+                t_split = None
+            if t_split is not None and t_split < 0.8 * t_full:
+                csplit, (ltw, lth, ltn), nslabs = 1, tile_s, ns_split
         # every weight-gradient launch owns its slab: its reduction runs on another lane while the next launch is already
         # writing (1.2 GB in total for BASELINE config 2 -- 0.4 % of the 288 GB of HBM)
         self.nwgrad = getattr(self, "nwgrad", 0) + 1

@@ -119,15 +119,19 @@ def _out_of(op):
 
 
 # the (3, 9, True, 8, 32) case makes the planner pick multi-image tiles with one-row halos (TH = 1, TN > 1) for the 1x1 head
-CASES = [(3, 9, True, 2, 32), (1, 2, True, 1, 32), (3, 3, False, 2, 32), (3, 9, True, 1, 64), (3, 1, False, 2, 64), (3, 9, True, 8, 32)]
+# (cin, cout, blindspot, B, P, cus): cus = 0 plans for the device's CU count; a small value plans persistent grids of that
+# many workgroups, so that the multi-tile paths of the weight-gradient kernel (double-buffered prefetch, compile-time K-step
+# schedule of the hot shapes) run at test sizes too -- at cus = 256 they only trigger from BASELINE config 2 upwards
+CASES = [(3, 9, True, 2, 32, 0), (1, 2, True, 1, 32, 0), (3, 3, False, 2, 32, 0), (3, 9, True, 1, 64, 0), (3, 1, False, 2, 64, 0),
+         (3, 9, True, 8, 32, 0), (3, 9, True, 2, 32, 8), (3, 3, False, 2, 64, 6)]
 
 
-@pytest.mark.parametrize("cin,cout,bs,B,P", CASES)
-def test_every_op_teacher_forced(cin, cout, bs, B, P):
+@pytest.mark.parametrize("cin,cout,bs,B,P,cus_plan", CASES)
+def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan):
     from ssdn.hip.engine import DeviceNet, OpList, current_stream
     from ssdn.hip.graph import NetPlan
     from ssdn.hip import lib as L
-    cus = L.load().ssdn_device_cus()
+    cus = cus_plan or L.load().ssdn_device_cus()
     p = R.make_params(cin, cout, bs, seed=7)
     plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=cus)
     flat = flat_params(plan, p)
@@ -219,7 +223,7 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P):
             dn.t[dst.t][..., dst.co:dst.co + ch] = ref.to(dev()).to(dn.t[dst.t].dtype)
         i += 1
     os.makedirs(OUTDIR, exist_ok=True)
-    with open(os.path.join(OUTDIR, "teacher_forced_%d_%d_%d_%d_%d.txt" % (cin, cout, int(bs), B, P)), "w") as f:
+    with open(os.path.join(OUTDIR, "teacher_forced_%d_%d_%d_%d_%d_cus%d.txt" % (cin, cout, int(bs), B, P, cus_plan)), "w") as f:
         f.write("\n".join(failures) if failures else "all %d ops OK\n" % len(ops))
     assert not failures, "\n".join(failures[:40])
 

@@ -76,7 +76,7 @@ def _validate_with_library(op):
         for i, (dy, dx) in enumerate(a["taps"]):
             s.dy[i], s.dx[i], s.coff[i] = dy, dx, a["coff"][i]
         s.M, s.Mpad, s.Ktot, s.Kpad, s.nslabs = a["M"], a["Mpad"], a["Ktot"], a["Kpad"], a["nslabs"]
-        s.ltw, s.lth, s.ltn = a["ltw"], a["lth"], a["ltn"]
+        s.ltw, s.lth, s.ltn, s.csplit = a["ltw"], a["lth"], a["ltn"], a.get("csplit", 0)
         rc = L.load().ssdn_wgrad_lds_bytes(C.byref(s))
     assert 0 <= rc <= 160 * 1024, (op.type, a["layer"], rc, L.load().ssdn_last_error())
 
@@ -84,9 +84,12 @@ def _validate_with_library(op):
 def test_plan_tilings_fit_lds():
     """every conv / wgrad tiling of the BASELINE configurations is accepted by the library and fits the 160 KiB LDS of a CU"""
     from ssdn.hip.graph import LDS_LIMIT
-    for (cin, cout, bs, B, P) in [(3, 9, True, 32, 64), (3, 9, True, 16, 128), (3, 3, False, 32, 64), (1, 1, False, 4, 32),
-                                  (3, 9, True, 2, 768), (3, 9, True, 2, 512)]:
-        plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=256, train=P <= 128)
+    # (the small CU counts make workgroups own several tiles at small sizes: multi-tile prefetch constraints, output split)
+    for (cin, cout, bs, B, P, cus) in [(3, 9, True, 32, 64, 256), (3, 9, True, 16, 128, 256), (3, 3, False, 32, 64, 256),
+                                       (1, 1, False, 4, 32, 256), (3, 9, True, 2, 768, 256), (3, 9, True, 2, 512, 256),
+                                       (3, 9, True, 2, 32, 8), (3, 3, False, 2, 64, 6), (1, 2, True, 1, 32, 3), (3, 9, True, 1, 32, 1),
+                                       (3, 9, True, 4, 64, 16), (3, 9, True, 2, 96, 256), (3, 9, True, 8, 64, 64)]:
+        plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=cus, train=P <= 128)
         for op in plan.fwd + plan.bwd:
             a = op.a
             if op.type in ("conv", "wgrad"):
