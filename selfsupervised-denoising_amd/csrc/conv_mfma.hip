@@ -561,9 +561,25 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
         e = getenv("SSDN_CONV_DESYNC");
         x.desync = e ? atoi(e) : 0;
     }
-    // output channels in launches of 96 (MT=3); the tail uses MT = 1 or 2
+    // output channels in blocks of 96 (MT=3); the tail uses MT = 1 or 2.  Layers with few pixel tiles are latency-bound (one
+    // workgroup's pass over its tile IS the launch): they run as blocks of 32 channels (MT=1) on three times as many
+    // workgroups, each with a third of the MFMA and epilogue work.
     int full = a->Mpad / 96, rem = (a->Mpad % 96) / 32;
     const bool bf = a->bf16 != 0;
+    // (measured per layer of BASELINE config 2: -20..-25 % up to one tile per CU, +35 % at two tiles per CU)
+    static int mt1_tiles = -1;
+    if (mt1_tiles < 0) {
+        const char* e = getenv("SSDN_CONV_MT1_TILES");       // tuning override
+        mt1_tiles = e ? atoi(e) : ssdn_device_cus();
+        if (mt1_tiles <= 0) mt1_tiles = 256;                  // no device (planning on a CPU-only host)
+    }
+    const int ntiles = g.tiles_x * g.tiles_y * g.groups_n;
+    if (!a->dst32 && ntiles <= mt1_tiles && a->Mpad >= 64) {
+        rc = bf ? conv_launch_ks<1, true>(a, g, x, a->Mpad / 32, s) : conv_launch_ks<1, false>(a, g, x, a->Mpad / 32, s);
+        if (rc) return rc;
+        SSDN_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
     if (full) {
         rc = bf ? conv_launch_ks<3, true>(a, g, x, full, s) : conv_launch_ks<3, false>(a, g, x, full, s);
         if (rc) return rc;
