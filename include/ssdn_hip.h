@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSDN_ABI_VERSION 2
+#define SSDN_ABI_VERSION 3
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -188,6 +188,10 @@ typedef struct ssdn_wgrad_args {
                               1: a workgroup owns 4 column tiles (32 input channels of one tap, or the bias column):
                                  grid = nslabs x ceil((ntaps*Kpad/32 + 1) / 4) -- for layers with few pixels, where
                                  writing a full slab per workgroup would dominate */
+    int32_t mblocks;       /* >= 1: the launch covers mblocks blocks of M output channels (dz channels [b*M, b*M+M) of the dz
+                              view, slabs [b*nslabs, (b+1)*nslabs) of `slab` / `bslab`): grid = mblocks x nslabs workgroups,
+                              the mblocks workgroups that stream the same pixels placed on one XCD so that the input tile
+                              reaches HBM once (1x1 head layers: 4 blocks of 96) */
 } ssdn_wgrad_args;
 
 /* ---- SSDN_OP_WREDUCE ------------------------------------------------------------------------

@@ -195,18 +195,24 @@ class Interp:
         self.store(dst, cpad, out)
 
     def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, coff, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn,
-                 slab=None, bslab=None, csplit=0):
+                 slab=None, bslab=None, csplit=0, mblocks=1):
         x = _r16(self._gather(src0, src1, c0, c1, up0, N, H, W), self.fp16, "bf16")   # staged as bf16 on the device
-        g = self.view(dz, M)
-        self.slab = torch.zeros(len(taps), Mpad, Kpad)
-        for t, (dy, dx) in enumerate(taps):
-            kw = min(Kpad, Ktot - coff[t])
-            self.slab[t, :M, :kw] = torch.einsum("nhwm,nhwk->mk", g, self._shift(x, dy, dx)[..., coff[t]:coff[t] + kw])
-        self.bslab = torch.zeros(Mpad)
-        self.bslab[:M] = g.sum((0, 1, 2))
+        self.slabs, self.bslabs = [], []
+        for mb in range(mblocks):        # a merged launch covers mblocks blocks of M output channels of the dz view
+            g = self.t[dz.t][..., dz.co + mb * M:dz.co + mb * M + M]
+            sl = torch.zeros(len(taps), Mpad, Kpad)
+            for t, (dy, dx) in enumerate(taps):
+                kw = min(Kpad, Ktot - coff[t])
+                sl[t, :M, :kw] = torch.einsum("nhwm,nhwk->mk", g, self._shift(x, dy, dx)[..., coff[t]:coff[t] + kw])
+            bs = torch.zeros(Mpad)
+            bs[:M] = g.sum((0, 1, 2))
+            self.slabs.append(sl)
+            self.bslabs.append(bs)
+        self.slab, self.bslab = self.slabs[0], self.bslabs[0]
 
     def op_wreduce(self, layer, nslabs, ntaps, M, Mpad, Kpad, cin, cin_full, m_off, c_off, with_bias, tapblock=0,
-                   slab=None, bslab=None):
+                   slab=None, bslab=None, mblock=0):
+        self.slab, self.bslab = self.slabs[mblock], self.bslabs[mblock]
         l = self.L[layer]
         base = self.plan.param_base
         gw = self.grads[base + l.w_off: base + l.w_off + l.M * l.cin * l.ntaps].reshape(l.M, l.cin, l.ntaps)

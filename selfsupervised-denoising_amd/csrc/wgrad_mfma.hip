@@ -149,6 +149,17 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, mh = (lane >> 4) & 1;
+    // Workgroup -> (pixel partition = slab index, block of M output channels).  Workgroups go to the 8 XCDs round-robin by
+    // id and every XCD has its own L2: the mblocks workgroups of one pixel partition get ids 8 apart, i.e. the same XCD,
+    // dispatched back to back -- they stream the same tiles in lock-step and share them through L2.
+    int wg_slab = blockIdx.x, wg_nslabs = gridDim.x, wg_mb = 0;
+    if (a.mblocks > 1) {
+        const unsigned j = blockIdx.x >> 3;
+        wg_mb = (int)(j % (unsigned)a.mblocks);
+        wg_slab = (int)(j / (unsigned)a.mblocks) * 8 + (int)(blockIdx.x & 7);
+        wg_nslabs = a.nslabs;
+        if (wg_slab >= a.nslabs) return;      // (grid is rounded up to a multiple of 8 partitions)
+    }
     const int NTt = a.Kpad >> 5;
     const int CT = a.ntaps * NTt;  // column tiles; tile index CT = the bias column
 
@@ -176,7 +187,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     const h16* sp = (const h16*)(use0 ? a.src0.p : a.src1.p);
     const int scs = use0 ? a.src0.cs : a.src1.cs, sco = use0 ? a.src0.co : a.src1.co, sh = use0 ? a.up0 : 0;
     const int Hs = a.H >> sh, Ws = a.W >> sh;
-    const h16* dzp = (const h16*)a.dz.p;
+    const h16* dzp = (const h16*)a.dz.p + wg_mb * a.M;     // (this block's channels of the dz view)
     const int npix_tile = g.TN * g.TH * g.TW;
     const int RX = g.TN * g.HH, RD = g.TN * g.TH;         // rows of the input halo image / of the dZ image
     const int rowx = g.HW * x.ccx, rowd = g.TW * x.ccd;   // 16-B pieces per row
@@ -216,10 +227,10 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
         *reinterpret_cast<u16x8*>(smem + 2 * bufsz + tid * 16) = o;
     }
     const int ksteps = npix_tile >> 4;
-    const int ntl = ((int)g.ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int ntl = ((int)g.ntiles - wg_slab + wg_nslabs - 1) / wg_nslabs;
 
     auto origin = [&](int i, int& n0, int& y0, int& x0) __attribute__((always_inline)) {
-        int bid = blockIdx.x + i * gridDim.x;
+        int bid = wg_slab + i * wg_nslabs;
         const int tx_i = bid % g.tiles_x; bid /= g.tiles_x;
         const int ty_i = bid % g.tiles_y; bid /= g.tiles_y;
         n0 = bid * g.TN; y0 = ty_i * g.TH; x0 = tx_i * g.TW;
@@ -550,7 +561,8 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     stamp();
     if constexpr (SPLIT) asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
     // ---- write this workgroup's slab: D row = m (8*(r>>2) + 4*kh + (r&3)), D col = k (l31) ----
-    float* slab = a.slab + (long long)blockIdx.x * a.ntaps * a.Mpad * a.Kpad;
+    const long long wg_sidx = (long long)wg_mb * a.nslabs + wg_slab;
+    float* slab = a.slab + wg_sidx * a.ntaps * a.Mpad * a.Kpad;
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
         if (!ct_on[j]) continue;
@@ -560,7 +572,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
             for (int r = 0; r < 16; ++r) {
                 int m = mt * 32 + 8 * (r >> 2) + 4 * kh + (r & 3);
                 if (ct_bias[j]) {
-                    if (l31 == 0) a.bslab[(long long)blockIdx.x * a.Mpad + m] = acc[mt][j][r];
+                    if (l31 == 0) a.bslab[wg_sidx * a.Mpad + m] = acc[mt][j][r];
                 } else {
                     slab[((long long)ct_tap[j] * a.Mpad + m) * a.Kpad + ct_nt[j] * 32 + l31] = acc[mt][j][r];
                 }
@@ -582,6 +594,8 @@ static int wgrad_validate(const ssdn_wgrad_args* a) {
     if (a->nslabs < 1) return ssdn_set_error("wgrad: nslabs < 1");
     if (a->c0 && a->c1) return ssdn_set_error("wgrad: one input tensor per launch (c0 == 0 or c1 == 0)");
     if (a->csplit != 0 && a->csplit != 1) return ssdn_set_error("wgrad: csplit must be 0 or 1");
+    if (a->mblocks < 0 || a->mblocks > 16) return ssdn_set_error("wgrad: mblocks must be 0..16 (0 = 1)");
+    if (a->mblocks > 1 && a->csplit) return ssdn_set_error("wgrad: mblocks > 1 and csplit exclude each other");
     if (a->c0 && a->up0 && (a->ltw < 1 || a->lth < 1)) return ssdn_set_error("wgrad: upsampled input needs even tile origins (tile >= 2x2)");
     return 0;
 }
@@ -623,7 +637,8 @@ static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& 
     double px = (double)a->N * a->H * a->W;
     prof_begin(SSDN_PROF_WGRAD, s);
     const int gy = a->csplit ? (a->ntaps * (a->Kpad / 32) + 1 + WG_WAVES - 1) / WG_WAVES : 1;
-    hipLaunchKernelGGL((k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>), dim3(a->nslabs, gy), dim3(WG_THREADS), lds, s, *a, x);
+    const int gx = a->mblocks > 1 ? ((a->nslabs + 7) / 8) * 8 * a->mblocks : a->nslabs;
+    hipLaunchKernelGGL((k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>), dim3(gx, gy), dim3(WG_THREADS), lds, s, *a, x);
     prof_end(SSDN_PROF_WGRAD, s, 2.0 * px * a->M * a->Ktot * a->ntaps, px * 2.0 * (a->M + a->Ktot));
     return 0;
 }

@@ -159,12 +159,17 @@ class DeviceNet:
             s.nslabs = a["nslabs"]
             s.ltw, s.lth, s.ltn = a["ltw"], a["lth"], a["ltn"]
             s.csplit = a.get("csplit", 0)
+            s.mblocks = a.get("mblocks", 1)
             if L.load().ssdn_wgrad_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("wgrad %s: %s" % (a["layer"], L.load().ssdn_last_error().decode()))
             return op.type, s
         if op.type == "wreduce":
             l = self._layer(a["layer"])
-            return op.type, L.WreduceArgs(_ptr(self.t[a["slab"]]), _ptr(self.t[a["bslab"]]), a["nslabs"], a["ntaps"], a["M"],
+            # (a merged weight-gradient launch owns mblocks consecutive groups of nslabs slabs: this reduction reads group mblock)
+            mb = a.get("mblock", 0)
+            soff = 4 * mb * a["nslabs"] * a["ntaps"] * a["Mpad"] * a["Kpad"]
+            boff = 4 * mb * a["nslabs"] * a["Mpad"]
+            return op.type, L.WreduceArgs(_ptr(self.t[a["slab"]], soff), _ptr(self.t[a["bslab"]], boff), a["nslabs"], a["ntaps"], a["M"],
                                           a["Mpad"], a["Kpad"], a["cin"], a["cin_full"], a["m_off"], a["c_off"], a["tapblock"],
                                           self._gp(l.w_off), self._gp(l.b_off) if a["with_bias"] else None,
                                           _ptr(self.t[P + "scale"], 4))

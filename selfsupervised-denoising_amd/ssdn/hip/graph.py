@@ -272,11 +272,13 @@ class NetPlan:
                                    dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"))))
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
-               m_off=0, c_off=0, with_bias=True, cblocks=None):
+               m_off=0, c_off=0, with_bias=True, cblocks=None, mblocks=1):
         """One SSDN_OP_WGRAD + SSDN_OP_WREDUCE pair covering output channels [m_off, m_off+M) x input channels
         [c_off, c_off+cin_real) of `layer` (M <= 96; Ktot <= 96 per tap).
         cblocks (1x1 layers only): list of channel offsets -- the kernel's "taps" become 96-channel blocks of the input,
-        so one launch covers M x len(cblocks)*96 weights."""
+        so one launch covers M x len(cblocks)*96 weights.
+        mblocks > 1: ONE launch covers mblocks consecutive blocks of Mz output channels (dz channels m_off + b*Mz ...), each
+        with its own group of slabs and its own reduction; the workgroups of the blocks share the input tiles through L2."""
         Ktot = c0 + c1
         Kpad = ceil_to(Ktot, 32) if cblocks is None else 96
         coff = [0] * len(taps) if cblocks is None else list(cblocks)
@@ -303,7 +305,7 @@ class NetPlan:
         t_full, tile_f, ns_full = candidate(1, 1300, 1.0)
         csplit = 0
         (ltw, lth, ltn), nslabs = tile_f, ns_full
-        if gy > 1 and not os.environ.get("SSDN_NO_CSPLIT"):
+        if gy > 1 and mblocks == 1 and not os.environ.get("SSDN_NO_CSPLIT"):
             try:
                 t_split, tile_s, ns_split = candidate(gy, 750, 1.0 / gy)
             except ValueError:          # no tile the fewer, fatter workgroups could prefetch
@@ -313,15 +315,17 @@ class NetPlan:
         # every weight-gradient launch owns its slab: its reduction runs on another lane while the next launch is already
         # writing (1.2 GB in total for BASELINE config 2 -- 0.4 % of the 288 GB of HBM)
         self.nwgrad = getattr(self, "nwgrad", 0) + 1
-        slab = self.T("slab%d" % self.nwgrad, "f32", (nslabs * ntaps * Mpad * Kpad,))
-        bslab = self.T("bslab%d" % self.nwgrad, "f32", (nslabs * Mpad,))
-        M_real = min(Mz, layer.M - m_off)
+        slab = self.T("slab%d" % self.nwgrad, "f32", (mblocks * nslabs * ntaps * Mpad * Kpad,))
+        bslab = self.T("bslab%d" % self.nwgrad, "f32", (mblocks * nslabs * Mpad,))
         self.bwd.append(Op("wgrad", dict(layer=layer.name, dz=dz, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                          taps=list(taps), coff=coff, M=Mz, Mpad=Mpad, Ktot=Ktot, Kpad=Kpad, nslabs=nslabs,
-                                         ltw=ltw, lth=lth, ltn=ltn, csplit=csplit, slab=slab, bslab=bslab)))
-        self.bwd.append(Op("wreduce", dict(layer=layer.name, nslabs=nslabs, ntaps=ntaps, M=M_real, Mpad=Mpad, Kpad=Kpad,
-                                           cin=cin_real, cin_full=layer.cin, m_off=m_off, c_off=c_off, with_bias=with_bias,
-                                           tapblock=int(cblocks is not None), slab=slab, bslab=bslab)))
+                                         ltw=ltw, lth=lth, ltn=ltn, csplit=csplit, mblocks=mblocks, slab=slab, bslab=bslab)))
+        for mb in range(mblocks):
+            mo = m_off + mb * Mz
+            M_real = min(Mz, layer.M - mo)
+            self.bwd.append(Op("wreduce", dict(layer=layer.name, nslabs=nslabs, ntaps=ntaps, M=M_real, Mpad=Mpad, Kpad=Kpad,
+                                               cin=cin_real, cin_full=layer.cin, m_off=mo, c_off=c_off, with_bias=with_bias,
+                                               tapblock=int(cblocks is not None), mblock=mb, slab=slab, bslab=bslab)))
 
     # ---- construction --------------------------------------------------------------------------------------
     def _build(self):
@@ -428,8 +432,7 @@ class NetPlan:
         dgrad("output_block.2", g_nb, 96, B, H, W, TAPS_1x1, nin, View(g_na), mask=View(na))
         # output_block.0 : nin -> nin
         lo0 = L["output_block.0"]
-        for mi in range(0, nin, 96):
-            self._wgrad(lo0, View(g_na, mi), 96, View(head_in), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, m_off=mi, cblocks=blocks)
+        self._wgrad(lo0, View(g_na), 96, View(head_in), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, cblocks=blocks, mblocks=nin // 96)
         g_d1b = self.grad("g_d1b", N, H, W, 96)
         if bs:
             g_u = self.grad("g_u", B, H, W, 384)

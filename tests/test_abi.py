@@ -16,7 +16,7 @@ def test_library_loads_and_exports_header_symbols():
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ssdn_abi_version() == 2
+    assert lib.ssdn_abi_version() == 3
 
 
 def test_struct_mirrors_match_compiler_layout():

@@ -163,31 +163,33 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan):
     while i < len(ops):
         op = ops[i]
         if op.type == "wgrad":
-            pair = [dn._mat(op), dn._mat(ops[i + 1])]
-            a2 = ops[i + 1].a
-            l = next(x for x in plan.layers if x.name == a2["layer"])
+            nred = op.a.get("mblocks", 1)            # a merged launch is followed by one reduction per block of output channels
+            group = [dn._mat(op)] + [dn._mat(ops[i + 1 + k]) for k in range(nred)]
+            l = next(x for x in plan.layers if x.name == ops[i + 1].a["layer"])
             dgrads.fill_(float("nan"))
             dn.t["m/scale"][0] = it.scale
             dn.t["m/scale"][1] = 1.0 / it.scale
-            OpList(pair).run(current_stream())
+            OpList(group).run(current_stream())
             torch.cuda.synchronize()
             gw = dgrads[l.w_off:l.w_off + l.M * l.cin * l.ntaps].cpu().reshape(l.M, l.cin, l.ntaps)
             rw = it.grads[l.w_off:l.w_off + l.M * l.cin * l.ntaps].reshape(l.M, l.cin, l.ntaps)
-            sl = (slice(a2["m_off"], a2["m_off"] + a2["M"]), slice(a2["c_off"], a2["c_off"] + a2["cin"]))
-            g, r = gw[sl], rw[sl]
-            # fp32 accumulation over up to 2^17 fp16 products in a different order: 1e-3 of the block's scale
-            tol = 1e-3 * float(r.abs().max()) + 1e-12
-            err = float((g - r).abs().max()) if torch.isfinite(g).all() else float("inf")
-            if not err <= tol:
-                failures.append("op %d wgrad %s m_off %d c_off %d: max err %.3e (tol %.3e)" % (i, l.name, a2["m_off"], a2["c_off"], err, tol))
-            if a2["with_bias"]:
-                gb = dgrads[l.b_off + a2["m_off"]: l.b_off + a2["m_off"] + a2["M"]].cpu()
-                rb = it.grads[l.b_off + a2["m_off"]: l.b_off + a2["m_off"] + a2["M"]]
-                tolb = 1e-3 * float(rb.abs().max()) + 1e-12
-                errb = float((gb - rb).abs().max()) if torch.isfinite(gb).all() else float("inf")
-                if not errb <= tolb:
-                    failures.append("op %d bias-grad %s: max err %.3e (tol %.3e)" % (i, l.name, errb, tolb))
-            i += 2
+            for k in range(nred):
+                a2 = ops[i + 1 + k].a
+                sl = (slice(a2["m_off"], a2["m_off"] + a2["M"]), slice(a2["c_off"], a2["c_off"] + a2["cin"]))
+                g, r = gw[sl], rw[sl]
+                # fp32 accumulation over up to 2^17 fp16 products in a different order: 1e-3 of the block's scale
+                tol = 1e-3 * float(r.abs().max()) + 1e-12
+                err = float((g - r).abs().max()) if torch.isfinite(g).all() else float("inf")
+                if not err <= tol:
+                    failures.append("op %d wgrad %s m_off %d c_off %d: max err %.3e (tol %.3e)" % (i, l.name, a2["m_off"], a2["c_off"], err, tol))
+                if a2["with_bias"]:
+                    gb = dgrads[l.b_off + a2["m_off"]: l.b_off + a2["m_off"] + a2["M"]].cpu()
+                    rb = it.grads[l.b_off + a2["m_off"]: l.b_off + a2["m_off"] + a2["M"]]
+                    tolb = 1e-3 * float(rb.abs().max()) + 1e-12
+                    errb = float((gb - rb).abs().max()) if torch.isfinite(gb).all() else float("inf")
+                    if not errb <= tolb:
+                        failures.append("op %d bias-grad %s: max err %.3e (tol %.3e)" % (i, l.name, errb, tolb))
+            i += 1 + nred
             continue
         kind, dst, ch = _out_of(op)
         rec = dn._mat(op)
