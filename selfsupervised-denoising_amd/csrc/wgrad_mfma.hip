@@ -330,7 +330,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
             for (int r = 0; r < 16; ++r) acc[mt][j][r] = 0.f;
 
     half8 pvA[NPV], pvB[NPV], pvC[KS > 0 ? NPV : 1];
-    int rlA = -1, rlB = -1, rdA = -1, rdB = -1, rlC = -1;   // LDS row offsets of the items in flight (-1: none); rd*: dZ item
+    int rlA = -1, rlB = -1, rdA = -1, rdB = -1, rlC = -1, rdC = -1;   // LDS row offsets of the items in flight (-1: none); rd*: dZ item
 #pragma unroll
     for (int u = 0; u < NPV; ++u) pvA[u] = pvB[u] = zero_h8();
     pvC[0] = zero_h8();
@@ -487,22 +487,34 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
             // input rows first, then dZ rows) and what it writes to LDS (the item of K-step ks-2): no branches, no selects.  A
             // wave whose row index is past the tile (the row count need not divide by 4) loads zeros and writes them to the
             // image's dummy row.
+            // BOTH (wide rows, 1x1 layers): K-step ks loads input row ks AND dZ row ks, prefetch distance 2.
             const int xsx = ((x0 >> sh) * scs) * 2, xsd = x0 * a.dz.cs * 2;
+            constexpr int DIST = BOTH ? 2 : 3;          // K-steps between a row's loads and its LDS writes
+            constexpr int DO = BOTH ? NL : 0;           // first dZ piece inside a prefetch register set
+            static_assert((BOTH ? (RWX > RWD ? RWX : RWD) : RWX + RWD) + DIST <= KS, "row items must be committed within their tile");
             static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(Kc)::value;
-                constexpr int LK = ks < RWX ? 1 : ks < RWX + RWD ? 2 : 0;                       // loaded in this K-step
-                constexpr int CK = ks < 3 ? 0 : ks - 3 < RWX ? 1 : ks - 3 < RWX + RWD ? 2 : 0;    // committed in this K-step
-                static_assert(RWX + RWD + 3 <= KS, "row items must be committed within their tile");
+                constexpr int kc = ks - DIST;               // the K-step whose loads are written to LDS now
+                constexpr bool LX = BOTH ? ks < RWX : ks < RWX;                              // loaded in this K-step
+                constexpr bool LD = BOTH ? ks < RWD : (ks >= RWX && ks < RWX + RWD);
+                constexpr bool CX = kc >= 0 && (BOTH ? kc < RWX : kc < RWX);                 // committed in this K-step
+                constexpr bool CD = kc >= 0 && (BOTH ? kc < RWD : (kc >= RWX && kc < RWX + RWD));
+                constexpr int rsx = ks, rsd = BOTH ? ks : ks - RWX;                          // row slots of the loads
                 half8* afc = (ks & 1) ? afB : afA;
                 half8* afn = (ks & 1) ? afA : afB;
-                half8* pv = ks % 3 == 0 ? pvA : ks % 3 == 1 ? pvB : pvC;      // prefetch distance: 3 K-steps
-                int& ro = ks % 3 == 0 ? rlA : ks % 3 == 1 ? rlB : rlC;        // LDS byte offset (inside an image) of the set's row
+                half8* pv = ks % DIST == 0 ? pvA : ks % DIST == 1 ? pvB : pvC;
+                int& rox = ks % DIST == 0 ? rlA : ks % DIST == 1 ? rlB : rlC;   // LDS byte offsets (inside an image) of the set's rows
+                int& rod = ks % DIST == 0 ? rdA : ks % DIST == 1 ? rdB : rdC;
                 constexpr int kn = (ks + 1) % KS;
                 const char* ab = abase(kn);
                 const char* xb = xbase(kn);
-                const h16* nbase = dzp;
-                int nnum = 0;
-                constexpr int SLOTS = MT * CPW, NSIDE = 2 * NPV + 1;
+                const h16* nbx = dzp;
+                const h16* nbd = dzp;
+                int nnx = 0, nnd = 0;
+                // side items in issue order: LDS writes of the old rows, then description + loads of the new rows
+                constexpr int NCX = CX ? NL : 0, NCD = CD ? WG_ND : 0, NLX = LX ? NL + 1 : 0, NLD = LD ? WG_ND + 1 : 0;
+                constexpr int NSIDE = NCX + NCD + NLX + NLD;
+                constexpr int SLOTS = MT * CPW;
                 static_for<0, SLOTS>([&](auto Sc) __attribute__((always_inline)) {
                     constexpr int S = decltype(Sc)::value, j = S / MT, mt = S % MT;
                     mma(std::integral_constant<int, j>{}, std::integral_constant<int, mt>{}, afc);
@@ -512,35 +524,42 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
                     }
                     static_for<0, NSIDE>([&](auto Wc) __attribute__((always_inline)) {
                         constexpr int w = decltype(Wc)::value;
-                        constexpr int sl = SLOTS - MT >= NSIDE ? MT + w * (SLOTS - MT) / NSIDE : SLOTS - 1;
+                        constexpr int sl = SLOTS - MT >= NSIDE ? MT + w * (SLOTS - MT) / NSIDE : MT + (w * (SLOTS - MT)) / NSIDE;
                         if constexpr (sl == S) {
-                            if constexpr (w < NPV) {
-                                if constexpr (CK == 1 && w < NL) put_x(img_n, ro, w, pv[w]);
-                                if constexpr (CK == 2 && w < WG_ND) put_d(img_n, ro, w, pv[w]);
-                            } else if constexpr (w == NPV) {
-                                if constexpr (LK == 1) {
-                                    const int row = wave + WG_WAVES * ks;
+                            if constexpr (w < NCX) {
+                                put_x(img_n, rox, w, pv[w]);
+                            } else if constexpr (w < NCX + NCD) {
+                                put_d(img_n, rod, w - NCX, pv[DO + w - NCX]);
+                            } else if constexpr (w < NCX + NCD + NLX) {
+                                constexpr int u = w - NCX - NCD - 1;
+                                if constexpr (u < 0) {
+                                    const int row = wave + WG_WAVES * rsx;
                                     const bool valid = row < g.HH;
                                     const int y = y0 - g.padT + row;
                                     const bool ok = more && valid && (unsigned)y < (unsigned)a.H;
-                                    nbase = sp + (long long)((n0 * Hs + (y >> sh)) * Ws) * scs;
-                                    nnum = ok ? Ws * scs * 2 : 0;
-                                    ro = (valid ? row : g.HH) * g.HW * g.PSTR;
-                                } else if constexpr (LK == 2) {
-                                    const int row = wave + WG_WAVES * (ks - RWX);
+                                    nbx = sp + (long long)((n0 * Hs + (y >> sh)) * Ws) * scs;
+                                    nnx = ok ? Ws * scs * 2 : 0;
+                                    rox = (valid ? row : g.HH) * g.HW * g.PSTR;
+                                } else {
+                                    Row nrow;
+                                    nrow.base = nbx; nrow.num = nnx; nrow.lds = 0; nrow.xs = xsx;
+                                    pv[u] = load16(nrow, relx[u]);
+                                }
+                            } else {
+                                constexpr int u = w - NCX - NCD - NLX - 1;
+                                if constexpr (u < 0) {
+                                    const int row = wave + WG_WAVES * rsd;
                                     const bool valid = row < g.TH;
                                     const int y = y0 + row;
                                     const bool ok = more && valid && y < a.H;
-                                    nbase = dzp + (long long)((n0 * a.H + y) * a.W) * a.dz.cs;
-                                    nnum = ok ? a.W * a.dz.cs * 2 : 0;
-                                    ro = g.XB + (valid ? row : g.TH) * g.TW * g.DSTR;
+                                    nbd = dzp + (long long)((n0 * a.H + y) * a.W) * a.dz.cs;
+                                    nnd = ok ? a.W * a.dz.cs * 2 : 0;
+                                    rod = g.XB + (valid ? row : g.TH) * g.TW * g.DSTR;
+                                } else {
+                                    Row nrow;
+                                    nrow.base = nbd; nrow.num = nnd; nrow.lds = 0; nrow.xs = xsd;
+                                    pv[DO + u] = load16(nrow, reld[u]);
                                 }
-                            } else {
-                                constexpr int u = w - NPV - 1;
-                                Row nrow;
-                                nrow.base = nbase; nrow.num = nnum; nrow.lds = 0;
-                                if constexpr (LK == 1 && u < NL) { nrow.xs = xsx; pv[u] = load16(nrow, relx[u]); }
-                                if constexpr (LK == 2 && u < WG_ND) { nrow.xs = xsd; pv[u] = load16(nrow, reld[u]); }
                             }
                         }
                     });
@@ -667,8 +686,11 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     const bool st = !wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs;
     const bool st8 = st && g.PSTR == 192 && ksteps == 8 && wi.rswx == 3 && wi.rswd == 2;
     const bool st16 = st && g.PSTR == 64 && ksteps == 16 && wi.rswx == 5 && wi.rswd == 4;
+    // 1x1 layers over four 96-channel input blocks: stride 832 B, 8x8 tiles -> 4 K-steps, an input row AND a dZ row per K-step
+    const bool st4b = wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
 #define WG_CASE(mt, cpw) if (MT == mt && CPW == cpw) { \
-        if (wi.both) rc = wgrad_launch<mt, cpw, 6, true, 0, 0, 0, 0>(a, g, x, s); \
+        if (st4b && mt == 3 && cpw == 4) rc = wgrad_launch<mt, cpw, 6, true, ((mt == 3 && cpw == 4) ? 832 : 0), ((mt == 3 && cpw == 4) ? 4 : 0), 2, 2>(a, g, x, s); \
+        else if (wi.both) rc = wgrad_launch<mt, cpw, 6, true, 0, 0, 0, 0>(a, g, x, s); \
         else if (st8 && mt >= 2 && (cpw == 5 || cpw == 7)) rc = wgrad_launch<mt, cpw, 4, false, 192, ((mt >= 2 && (cpw == 5 || cpw == 7)) ? 8 : 0), 3, 2>(a, g, x, s); \
         else if (st16 && mt >= 2 && cpw == 3) rc = wgrad_launch<mt, cpw, 4, false, 64, ((mt >= 2 && cpw == 3) ? 16 : 0), 5, 4>(a, g, x, s); \
         else rc = wgrad_launch<mt, cpw, 4, false, 0, 0, 0, 0>(a, g, x, s); \

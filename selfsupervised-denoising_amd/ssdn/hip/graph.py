@@ -207,7 +207,8 @@ def choose_wgrad_tile(N, H, W, taps, Kpad, Mpad, Ktot, M, cus, budget=LDS_LIMIT)
                 if not ((ix <= 4 and (single or rswx + rswd <= steps)) or
                         (ix <= 6 and (single or (rswx <= steps and rswd <= steps)))):
                     continue
-                key = (round(util, 3), TN * TH * TW, -NP, ltw)
+                # (ties: one image per tile -- the kernel's compile-time schedules need that)
+                key = (round(util, 3), TN * TH * TW, -NP, ltw, -ltn)
                 if best is None or key > best[0]:
                     best = (key, (ltw, lth, ltn), tiles)
     if best is None:
