@@ -688,11 +688,16 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     const bool st16 = st && g.PSTR == 64 && ksteps == 16 && wi.rswx == 5 && wi.rswd == 4;
     // 1x1 layers over four 96-channel input blocks: stride 832 B, 8x8 tiles -> 4 K-steps, an input row AND a dZ row per K-step
     const bool st4b = wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
+    // (a static variant is only instantiated for the (mt, cpw) it is used with: elsewhere its template arguments collapse to
+    //  the generic kernel's)
+#define WG_S8(mt, cpw) ((mt) >= 2 && ((cpw) == 5 || (cpw) == 7))
+#define WG_S16(mt, cpw) ((mt) >= 2 && (cpw) == 3)
+#define WG_S4B(mt, cpw) ((mt) == 3 && (cpw) == 4)
 #define WG_CASE(mt, cpw) if (MT == mt && CPW == cpw) { \
-        if (st4b && mt == 3 && cpw == 4) rc = wgrad_launch<mt, cpw, 6, true, ((mt == 3 && cpw == 4) ? 832 : 0), ((mt == 3 && cpw == 4) ? 4 : 0), 2, 2>(a, g, x, s); \
+        if (st4b && WG_S4B(mt, cpw)) rc = wgrad_launch<mt, cpw, 6, true, WG_S4B(mt, cpw) ? 832 : 0, WG_S4B(mt, cpw) ? 4 : 0, WG_S4B(mt, cpw) ? 2 : 0, WG_S4B(mt, cpw) ? 2 : 0>(a, g, x, s); \
         else if (wi.both) rc = wgrad_launch<mt, cpw, 6, true, 0, 0, 0, 0>(a, g, x, s); \
-        else if (st8 && mt >= 2 && (cpw == 5 || cpw == 7)) rc = wgrad_launch<mt, cpw, 4, false, 192, ((mt >= 2 && (cpw == 5 || cpw == 7)) ? 8 : 0), 3, 2>(a, g, x, s); \
-        else if (st16 && mt >= 2 && cpw == 3) rc = wgrad_launch<mt, cpw, 4, false, 64, ((mt >= 2 && cpw == 3) ? 16 : 0), 5, 4>(a, g, x, s); \
+        else if (st8 && WG_S8(mt, cpw)) rc = wgrad_launch<mt, cpw, 4, false, WG_S8(mt, cpw) ? 192 : 0, WG_S8(mt, cpw) ? 8 : 0, WG_S8(mt, cpw) ? 3 : 0, WG_S8(mt, cpw) ? 2 : 0>(a, g, x, s); \
+        else if (st16 && WG_S16(mt, cpw)) rc = wgrad_launch<mt, cpw, 4, false, WG_S16(mt, cpw) ? 64 : 0, WG_S16(mt, cpw) ? 16 : 0, WG_S16(mt, cpw) ? 5 : 0, WG_S16(mt, cpw) ? 4 : 0>(a, g, x, s); \
         else rc = wgrad_launch<mt, cpw, 4, false, 0, 0, 0, 0>(a, g, x, s); \
     } else
     WG_CASE(1, 1) WG_CASE(1, 2) WG_CASE(1, 3) WG_CASE(1, 4) WG_CASE(1, 5) WG_CASE(1, 6) WG_CASE(1, 7)
@@ -700,6 +705,9 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     WG_CASE(3, 1) WG_CASE(3, 2) WG_CASE(3, 3) WG_CASE(3, 4) WG_CASE(3, 5) WG_CASE(3, 6) WG_CASE(3, 7)
     rc = ssdn_set_error("wgrad: unsupported shape MT=%d CPW=%d", MT, CPW);
 #undef WG_CASE
+#undef WG_S8
+#undef WG_S16
+#undef WG_S4B
     if (rc) return rc;
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;
