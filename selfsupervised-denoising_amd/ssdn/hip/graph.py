@@ -194,7 +194,7 @@ def choose_wgrad_tile(N, H, W, taps, Kpad, Mpad, Ktot, M, cus, budget=LDS_LIMIT)
                 if lds > budget:
                     continue
                 # ... filled row by row: the rows of a tile are dealt to the kernel's 4 waves, a wave loads one row (<= 4
-                # 64-lane 16-byte loads for an input row, <= 3 for a dZ row) per 16-pixel K-step in all but the last two
+                # 64-lane 16-byte loads for an input row, <= 3 for a dZ row) per 16-pixel K-step in all but the last few
                 # K-steps of a tile -- or, for wide rows (<= 6 loads), an input AND a dZ row per K-step.  Irrelevant when no
                 # workgroup gets a second tile.
                 HH, HW = TH + padT + padB, TW + padL + padR
@@ -313,8 +313,8 @@ class NetPlan:
                 t_split = None
             if t_split is not None and t_split < 0.8 * t_full:
                 csplit, (ltw, lth, ltn), nslabs = 1, tile_s, ns_split
-        # every weight-gradient launch owns its slab: its reduction runs on another lane while the next launch is already
-        # writing (1.2 GB in total for BASELINE config 2 -- 0.4 % of the 288 GB of HBM)
+        # every weight-gradient launch owns its slab (1.2 GB in total for BASELINE config 2 -- 0.4 % of the 288 GB of HBM): no
+        # ordering between a launch and the reduction of an earlier one is ever needed
         self.nwgrad = getattr(self, "nwgrad", 0) + 1
         slab = self.T("slab%d" % self.nwgrad, "f32", (mblocks * nslabs * ntaps * Mpad * Kpad,))
         bslab = self.T("bslab%d" % self.nwgrad, "f32", (mblocks * nslabs * Mpad,))

@@ -114,6 +114,8 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
                  mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs)
 
 # every symbol include/ssdn_hip.h declares
+ABI_VERSION = 3      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride"]
@@ -156,7 +158,7 @@ def load() -> C.CDLL:
     lib.ssdn_profile_read.restype = C.c_int
     lib.ssdn_struct_size.argtypes = [C.c_int]
     lib.ssdn_struct_size.restype = C.c_int
-    if lib.ssdn_abi_version() != 3:
+    if lib.ssdn_abi_version() != ABI_VERSION:
         raise SsdnHipError("libssdn_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -16,7 +16,7 @@ def test_library_loads_and_exports_header_symbols():
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ssdn_abi_version() == 3
+    assert lib.ssdn_abi_version() == L.ABI_VERSION == 3
 
 
 def test_struct_mirrors_match_compiler_layout():
@@ -52,3 +52,12 @@ def test_missing_library_is_an_error_not_a_fallback(monkeypatch, tmp_path):
         assert False, "expected SsdnHipError"
     except L.SsdnHipError as e:
         assert "no CPU fallback" in str(e)
+
+
+def test_graft_entry_build_is_consistent():
+    """the driver's build check: __graft_entry__.build() (make + import + ABI assertion) succeeds on a CPU-only host"""
+    import importlib
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    g = importlib.import_module("__graft_entry__")
+    g.build()
