@@ -48,7 +48,9 @@ def _worker(rank, world, port, out):
     flat2 = _flat_grad(tr)
     scale2 = ar(flat2)                       # monolithic form
     if rank == 0:
-        out.put((flat * scale, flat2 * scale2))
+        # numpy, not torch tensors: a tensor in a Queue is shared through a file descriptor the consumer must fetch from
+        # THIS process, which may already have exited when a loaded host gets round to unpickling (EOFError)
+        out.put(((flat * scale).numpy(), (flat2 * scale2).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -79,14 +81,18 @@ def _run_world(world):
 
 
 def test_two_rank_gradient_equals_single_process():
-    got_bucketed, got_mono = _run_world(2)
+    got_bucketed, got_mono = (torch.from_numpy(a) for a in _run_world(2))
     B, P = 4, 32
     tr = R.CpuTrainer("n2c", 1, seed=3)
     res = tr.forward(R.hash_tensor((B, 1, P, P), 5, 0, 1), R.hash_tensor((B, 1, P, P), 6, 0, 1))
     res["loss"].mean().backward()
     want = _flat_grad(tr)
-    assert torch.allclose(got_bucketed, want, rtol=1e-4, atol=1e-7)
-    assert torch.allclose(got_mono, want, rtol=1e-4, atol=1e-7)
+    # fp32 CPU convolutions sum in a thread-partition dependent order (2 threads per rank vs the parent's pool; the split can
+    # change with host load): tolerance relative to the gradient's scale, not to each element
+    tol = 2e-5 * float(want.abs().max())
+    assert float((got_bucketed - want).abs().max()) <= tol
+    assert float((got_mono - want).abs().max()) <= tol
+    assert torch.equal(got_bucketed, got_mono)      # the two exchange forms are the same sums
 
 
 def test_shard_rows_partition():
