@@ -477,12 +477,26 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     stamp();
 }
 
+// Layers with at most one pixel tile per CU are latency-bound (one workgroup's pass over its tile IS the launch): they run as
+// blocks of 32 output channels (MT = 1) on three times as many workgroups -- and may then take all 96 input channels of a
+// chunk at once (kc = 96: half the pipeline steps, no second tile staging).
+// (measured per layer of BASELINE config 2: -20..-25 % up to one tile per CU, +35 % at two tiles per CU)
+static bool conv_uses_mt1(const ssdn_conv_args* a, const ConvGeom& g) {
+    static int mt1_tiles = -1;
+    if (mt1_tiles < 0) {
+        const char* e = getenv("SSDN_CONV_MT1_TILES");       // tuning override
+        mt1_tiles = e ? atoi(e) : ssdn_device_cus();
+        if (mt1_tiles <= 0) mt1_tiles = 256;                  // no device (planning on a CPU-only host)
+    }
+    return !a->dst32 && g.tiles_x * g.tiles_y * g.groups_n <= mt1_tiles && a->Mpad >= 64;
+}
+
 static int conv_validate(const ssdn_conv_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("conv: ntaps out of range");
     if (a->ltw + a->lth + a->ltn > 9 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 512 pixels");
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 15)) return ssdn_set_error("conv: Ktot must equal c0+c1 and be a multiple of 16");
     if ((a->c0 & 7) || (a->c1 & 7)) return ssdn_set_error("conv: source channel counts must be multiples of 8");
-    if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc || a->kc > 64) return ssdn_set_error("conv: kc must be 16, 32, 48 or 64 and divide Ktot");
+    if (a->kc < 16 || (a->kc & 15) || a->Ktot % a->kc || (a->kc > 64 && a->kc != 96)) return ssdn_set_error("conv: kc must be 16, 32, 48, 64 or 96 and divide Ktot");
     if ((a->Mpad & 31) || a->M > a->Mpad) return ssdn_set_error("conv: Mpad must be a multiple of 32 and >= M");
     if (!a->dst32 && ((a->M & 7) || (a->dst.co & 7) || (a->dst.cs & 7))) return ssdn_set_error("conv: 16-bit output needs M, dst.co, dst.cs %% 8 == 0");
     if (a->add.p && ((a->add.co & 7) || (a->add.cs & 7))) return ssdn_set_error("conv: add view must be 16-byte aligned");
@@ -506,6 +520,8 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     int mt = a->Mpad / 32;
     if (mt > 3) mt = 3;
+    if (conv_uses_mt1(a, g)) mt = 1;
+    else if (a->kc == 96) { ssdn_set_error("conv: kc = 96 is only built for layers that run as 32-channel blocks (<= 1 tile per CU)"); return -1; }
     return (int)conv_lds(a, g, mt);
 }
 
@@ -542,6 +558,9 @@ static int conv_launch_ks(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
         case 48: return wide ? conv_launch_mt<MT, BF, 3, 512>(a, g, x, nblk_y, s) : conv_launch_mt<MT, BF, 3, 256>(a, g, x, nblk_y, s);
         case 64: return wide ? conv_launch_mt<MT, BF, 4, 512>(a, g, x, nblk_y, s) : conv_launch_mt<MT, BF, 4, 256>(a, g, x, nblk_y, s);
     }
+    if constexpr (MT == 1) {
+        if (a->kc == 96 && !wide) return conv_launch_mt<1, BF, 6, 256>(a, g, x, nblk_y, s);
+    }
     return ssdn_set_error("conv: unsupported kc %d", a->kc);
 }
 
@@ -566,15 +585,7 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     // workgroups, each with a third of the MFMA and epilogue work.
     int full = a->Mpad / 96, rem = (a->Mpad % 96) / 32;
     const bool bf = a->bf16 != 0;
-    // (measured per layer of BASELINE config 2: -20..-25 % up to one tile per CU, +35 % at two tiles per CU)
-    static int mt1_tiles = -1;
-    if (mt1_tiles < 0) {
-        const char* e = getenv("SSDN_CONV_MT1_TILES");       // tuning override
-        mt1_tiles = e ? atoi(e) : ssdn_device_cus();
-        if (mt1_tiles <= 0) mt1_tiles = 256;                  // no device (planning on a CPU-only host)
-    }
-    const int ntiles = g.tiles_x * g.tiles_y * g.groups_n;
-    if (!a->dst32 && ntiles <= mt1_tiles && a->Mpad >= 64) {
+    if (conv_uses_mt1(a, g)) {
         rc = bf ? conv_launch_ks<1, true>(a, g, x, a->Mpad / 32, s) : conv_launch_ks<1, false>(a, g, x, a->Mpad / 32, s);
         if (rc) return rc;
         SSDN_CHECK_HIP(hipGetLastError());

@@ -137,13 +137,12 @@ def _pow2ceil_log(v: int) -> int:
     return l
 
 
-def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
-    """Pick (ltw, lth, ltn, kc) for SSDN_OP_CONV: <= 256 pixels per workgroup, LDS = halo tile + two weight slices."""
+def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True, cus=256):
+    """Pick (ltw, lth, ltn, kc) for SSDN_OP_CONV: <= 256 pixels per workgroup, LDS = halo tile + two weight slices.
+    Layers with at most one pixel tile per CU run as 32-output-channel blocks (the library's rule, conv_uses_mt1): one
+    workgroup per CU at most, so LDS per workgroup does not matter and the whole 96-channel chunk is staged at once."""
     padT, padB, padL, padR = _pads(taps)
-    mt = min(3, Mpad // 32)
     best = None
-    # channel chunks the kernel is instantiated for (KS = kc/16 is a template parameter of k_conv)
-    kcs = [kc for kc in (16, 32, 48, 64) if Ktot % kc == 0]
     for ltw in range(0, min(5, _pow2ceil_log(W)) + 1):
         for lth in range(0, min(8 - ltw, _pow2ceil_log(H)) + 1):
             for ltn in range(0, min(8 - ltw - lth, _pow2ceil_log(N)) + 1):
@@ -151,6 +150,10 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
                 tiles = -(-W // TW) * -(-H // TH) * -(-N // TN)
                 util = (N * H * W) / (tiles * 256.0)       # MFMA lanes doing useful work
                 NP = TN * (TH + padT + padB) * (TW + padL + padR)
+                mt1 = out16 and tiles <= cus and Mpad >= 64
+                mt = 1 if mt1 else min(3, Mpad // 32)
+                # channel chunks the kernel is instantiated for (KS = kc/16 is a template parameter of k_conv)
+                kcs = [kc for kc in ((16, 32, 48, 64, 96) if mt1 else (16, 32, 48, 64)) if Ktot % kc == 0]
                 for kc in kcs:
                     lds = NP * (kc * 2 + 16) + 2 * mt * 32 * (kc * 2 + 16)
                     if len(taps) == 1 and Ktot // kc >= 2:   # 1x1 layers may run the two-buffer asynchronous tile pipeline
@@ -162,7 +165,7 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True):
                     halo = NP / float(TN * TH * TW)
                     # prefer: high utilisation, then 2 workgroups per CU, then large channel chunks (fewer barriers),
                     # then small halo, then wide tiles
-                    key = (round(util, 3), lds <= CONV_LDS_PREFERRED and kc >= min(48, Ktot), kc, -round(halo, 3), ltw)
+                    key = (round(util, 3), mt1 or (lds <= CONV_LDS_PREFERRED and kc >= min(48, Ktot)), kc, -round(halo, 3), ltw)
                     if best is None or key > best[0]:
                         best = (key, (ltw, lth, ltn, kc))
     if best is None:
@@ -267,7 +270,7 @@ class NetPlan:
               bias=True, act=True, mask=None, add=None):
         Ktot = c0 + c1
         Mpad = ceil_to(M, 32)
-        ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None)
+        ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None, cus=self.cus)
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                    taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
                                    dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"))))
