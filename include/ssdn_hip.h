@@ -184,10 +184,10 @@ typedef struct ssdn_wgrad_args {
     float* bslab;
     int32_t nslabs;
     int32_t ltw, lth, ltn; /* pixel tile per iteration: 2^ltn x 2^lth x 2^ltw */
-    int32_t csplit;        /* 0: a workgroup owns every column tile of the output (grid = nslabs);
-                              1: a workgroup owns 4 column tiles (32 input channels of one tap, or the bias column):
-                                 grid = nslabs x ceil((ntaps*Kpad/32 + 1) / 4) -- for layers with few pixels, where
-                                 writing a full slab per workgroup would dominate */
+    int32_t csplit;        /* column groups G (0 or 1: none).  The output is ntaps*Kpad/32 + 1 column tiles of 32 (tile 0 = the
+                              bias column); with G > 1 a workgroup owns ceil(tiles / G) consecutive ones and the grid is
+                              nslabs x G: for layers with few pixels, where writing a full slab per workgroup (~10 B per
+                              clock per CU) and reading it back would dominate */
     int32_t mblocks;       /* >= 1: the launch covers mblocks blocks of M output channels (dz channels [b*M, b*M+M) of the dz
                               view, slabs [b*nslabs, (b+1)*nslabs) of `slab` / `bslab`): grid = mblocks x nslabs workgroups,
                               the mblocks workgroups that stream the same pixels placed on one XCD so that the input tile

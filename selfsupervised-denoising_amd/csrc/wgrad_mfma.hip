@@ -163,24 +163,26 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     const int NTt = a.Kpad >> 5;
     const int CT = a.ntaps * NTt;  // column tiles; tile index CT = the bias column
 
-    // column tiles of this wave: ct = wave + 4 j.  Tiles j < CPW-1 always exist and are weight columns (4 (CPW-1) <= CT);
-    // only the last one can be the bias column (its B operand is the constant 1, never refilled) or absent.
+    // Column tiles: 0 = the bias column (B operand = the constant 1), 1 .. CT = (tap, 32-channel block) weight columns.  A
+    // workgroup owns the 4*CPW consecutive tiles of group blockIdx.y (csplit groups; one group = everything), dealt to its
+    // waves as ct = group base + wave + 4 j.  With the bias column FIRST it can only ever be (group 0, wave 0, j = 0), for any
+    // number of groups; tiles past CT are absent (computed like tap 0, never written).
     int ct_tap[CPW], ct_nt[CPW];
     bool ct_on[CPW], ct_bias[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-        int ct = blockIdx.y * (WG_WAVES * CPW) + wave + WG_WAVES * j;   // (gridDim.y > 1: csplit, CPW == 1)
+        const int ct = blockIdx.y * (WG_WAVES * CPW) + wave + WG_WAVES * j;
         ct_on[j] = ct <= CT;
-        ct_bias[j] = ct == CT;
-        int tp = ct_on[j] && !ct_bias[j] ? ct / NTt : 0;
-        ct_tap[j] = tp;
-        ct_nt[j] = ct_on[j] && !ct_bias[j] ? ct - tp * NTt : 0;
+        ct_bias[j] = ct == 0;
+        const int wt = ct_on[j] && !ct_bias[j] ? ct - 1 : 0;
+        ct_tap[j] = wt / NTt;
+        ct_nt[j] = wt - ct_tap[j] * NTt;
     }
     int stoff[CPW];   // wave-uniform LDS byte offset of the column tile's (tap, 32-channel block) relative to a halo pixel
 #pragma unroll
     for (int j = 0; j < CPW; ++j)
         stoff[j] = (a.dy[ct_tap[j]] * g.HW + a.dx[ct_tap[j]]) * g.PSTR + (a.coff[ct_tap[j]] + ct_nt[j] * 32) * 2;
-    const bool last_bias = ct_bias[CPW - 1];   // (an absent last column tile is computed like tap 0 and never written)
+    const bool first_bias = ct_bias[0];
 
     // the input of one launch comes from ONE tensor (src0, optionally read through the 2x nearest upsampling, or src1)
     const bool use0 = a.c0 > 0;
@@ -350,9 +352,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
         xlane[r] = ((tnl * g.HH + tyl) * g.HW + tx + g.padL) * g.PSTR + (i16 & 3) * 8;
     }
 
-    int xl_last[2];   // per-lane part of the last column tile's fragment address
+    int xl_first[2];   // per-lane part of the first column tile's fragment address (the bias column reads the area of ones)
 #pragma unroll
-    for (int r = 0; r < 2; ++r) xl_last[r] = last_bias ? lane * 8 : xlane[r] + mh * 32;
+    for (int r = 0; r < 2; ++r) xl_first[r] = first_bias ? lane * 8 : xlane[r] + mh * 32;
 
     for (int i = 0; i < ntl; ++i) {
         const char* xt_c = smem + (i & 1) * bufsz;
@@ -377,11 +379,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
         };
         auto read_b = [&](const char* xb, int j) __attribute__((always_inline)) -> half8 {
             // (the bias column reads the area of ones instead: scalar select of the base, per-lane part chosen once)
-            const bool ones = j == CPW - 1 && last_bias;
+            const bool ones = j == 0 && first_bias;
             const char* sb = ones ? smem + 2 * bufsz : xb + stoff[j];
-            const char* p0 = sb + (j == CPW - 1 ? xl_last[0] : xlane[0] + mh * 32);
+            const char* p0 = sb + (j == 0 ? xl_first[0] : xlane[0] + mh * 32);
             if constexpr (PS > 0) return cat8(tr16(p0), tr16(p0 + 4 * PS));
-            else return cat8(tr16(p0), tr16(sb + (j == CPW - 1 ? xl_last[1] : xlane[1] + mh * 32)));
+            else return cat8(tr16(p0), tr16(sb + (j == 0 ? xl_first[1] : xlane[1] + mh * 32)));
         };
         auto mma = [&](auto Jc, auto Mc, const half8* afc) __attribute__((always_inline)) {
             constexpr int j = decltype(Jc)::value, mt = decltype(Mc)::value;
@@ -612,9 +614,9 @@ static int wgrad_validate(const ssdn_wgrad_args* a) {
     if ((a->Mpad & 31) || a->Mpad > 96 || a->M > a->Mpad || (a->M & 7)) return ssdn_set_error("wgrad: Mpad must be 32/64/96, M %% 8 == 0");
     if (a->nslabs < 1) return ssdn_set_error("wgrad: nslabs < 1");
     if (a->c0 && a->c1) return ssdn_set_error("wgrad: one input tensor per launch (c0 == 0 or c1 == 0)");
-    if (a->csplit != 0 && a->csplit != 1) return ssdn_set_error("wgrad: csplit must be 0 or 1");
+    if (a->csplit < 0 || a->csplit > 32) return ssdn_set_error("wgrad: csplit (column groups) must be 0..32");
     if (a->mblocks < 0 || a->mblocks > 16) return ssdn_set_error("wgrad: mblocks must be 0..16 (0 = 1)");
-    if (a->mblocks > 1 && a->csplit) return ssdn_set_error("wgrad: mblocks > 1 and csplit exclude each other");
+    if (a->mblocks > 1 && a->csplit > 1) return ssdn_set_error("wgrad: mblocks > 1 and csplit > 1 exclude each other");
     if (a->c0 && a->up0 && (a->ltw < 1 || a->lth < 1)) return ssdn_set_error("wgrad: upsampled input needs even tile origins (tile >= 2x2)");
     return 0;
 }
@@ -655,7 +657,7 @@ static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& 
     }
     double px = (double)a->N * a->H * a->W;
     prof_begin(SSDN_PROF_WGRAD, s);
-    const int gy = a->csplit ? (a->ntaps * (a->Kpad / 32) + 1 + WG_WAVES - 1) / WG_WAVES : 1;
+    const int gy = a->csplit > 1 ? a->csplit : 1;
     const int gx = a->mblocks > 1 ? ((a->nslabs + 7) / 8) * 8 * a->mblocks : a->nslabs;
     hipLaunchKernelGGL((k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>), dim3(gx, gy), dim3(WG_THREADS), lds, s, *a, x);
     prof_end(SSDN_PROF_WGRAD, s, 2.0 * px * a->M * a->Ktot * a->ntaps, px * 2.0 * (a->M + a->Ktot));
@@ -678,7 +680,8 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     x.rswx = wi.rswx; x.rswd = wi.rswd;
     const int MT = a->Mpad / 32;
     const int CT = a->ntaps * (a->Kpad / 32) + 1;
-    const int CPW = a->csplit ? 1 : (CT + WG_WAVES - 1) / WG_WAVES;
+    const int gy = a->csplit > 1 ? a->csplit : 1;
+    const int CPW = (CT + WG_WAVES * gy - 1) / (WG_WAVES * gy);   // column tiles per wave (gy = column groups)
     // the hot shapes get the input pixel stride and the whole staging schedule as compile-time constants:
     //   3x3, 48..96 input channels: stride 192 B, 16x8 tiles  -> 8 K-steps, 3 input + 2 dZ rows per wave
     //   3x3, 16..32 input channels: stride  64 B, 16x16 tiles -> 16 K-steps, 5 + 4 rows per wave
@@ -690,8 +693,8 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     const bool st4b = wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
     // (a static variant is only instantiated for the (mt, cpw) it is used with: elsewhere its template arguments collapse to
     //  the generic kernel's)
-#define WG_S8(mt, cpw) ((mt) >= 2 && ((cpw) == 5 || (cpw) == 7))
-#define WG_S16(mt, cpw) ((mt) >= 2 && (cpw) == 3)
+#define WG_S8(mt, cpw) ((mt) >= 2 && (cpw) >= 2)
+#define WG_S16(mt, cpw) ((mt) >= 2 && (cpw) <= 3)
 #define WG_S4B(mt, cpw) ((mt) == 3 && (cpw) == 4)
 #define WG_CASE(mt, cpw) if (MT == mt && CPW == cpw) { \
         if (st4b && WG_S4B(mt, cpw)) rc = wgrad_launch<mt, cpw, 6, true, WG_S4B(mt, cpw) ? 832 : 0, WG_S4B(mt, cpw) ? 4 : 0, WG_S4B(mt, cpw) ? 2 : 0, WG_S4B(mt, cpw) ? 2 : 0>(a, g, x, s); \

@@ -290,32 +290,39 @@ class NetPlan:
             taps = [(0, 0)] * len(cblocks)
         Mpad = ceil_to(Mz, 32)
         ntaps = len(taps)
-        # Split of the work over workgroups.  Every workgroup ends by writing its accumulators as one fp32 slab, at ~10 B
-        # per clock per CU -- for the full [ntaps][Mpad][Kpad] output that is ~33 K cycles, more than the matrix work of a
-        # layer with few pixels.  Such layers split the OUTPUT instead (csplit: 4 column tiles per workgroup, every
-        # workgroup staging all of its pixel tiles); cycle model measured on the device: a 16-pixel K-step costs ~1300
-        # cycles with all column tiles, ~750 (staging-bound) with 4.  (The tile is chosen for the number of workgroups that
-        # share the pixels: a workgroup with several tiles needs a tile it can prefetch.)
-        slab_cyc = ntaps * Mpad * Kpad * 4 / 10.0
-        gy = -(-(ntaps * Kpad // 32 + 1) // 4)
+        # Split of the work over workgroups.  Every workgroup ends by writing its accumulators as one fp32 slab at ~10 B per
+        # clock per CU (~33 K cycles for the full [ntaps][Mpad][Kpad] output) and the reduction reads all slabs back -- more
+        # than the matrix work of a layer with few pixels.  Such layers split the OUTPUT into G column groups (csplit):
+        # cus // G pixel partitions, each workgroup staging its partition's tiles for 1/G of the columns.  Cycle model
+        # measured on the device: a 16-pixel K-step costs ~660 + 90 * (column tiles per wave) cycles (staging-bound floor ..
+        # 21-MFMA K-step); slab write slab/10 B per cycle per workgroup; reduction ~1900 B per cycle for all slabs.
+        # (The tile is chosen for the number of workgroups that share the pixels: a workgroup with several tiles needs a
+        # tile it can prefetch.)
+        slab_bytes = ntaps * Mpad * Kpad * 4
+        ctiles = ntaps * Kpad // 32 + 1
 
-        def candidate(groups, kstep_cyc, slab_share):
-            cus_eff = max(1, self.cus // groups)
+        def candidate(G):
+            cpw = -(-ctiles // (4 * G))
+            cus_eff = max(1, self.cus // G)
             tile, ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad, Ktot, Mz, cus_eff)
             ns = max(1, min(ntiles, cus_eff))
             ksteps = (1 << sum(tile)) // 16
-            return -(-ntiles // ns) * ksteps * kstep_cyc + slab_cyc * slab_share, tile, ns
+            t = -(-ntiles // ns) * ksteps * (660 + 90 * cpw) + slab_bytes / 10.0 / G + ns * slab_bytes / 1900.0
+            return t, tile, ns
 
-        t_full, tile_f, ns_full = candidate(1, 1300, 1.0)
-        csplit = 0
-        (ltw, lth, ltn), nslabs = tile_f, ns_full
-        if gy > 1 and mblocks == 1 and not os.environ.get("SSDN_NO_CSPLIT"):
+        best = None
+        groups = [1] if (mblocks > 1 or os.environ.get("SSDN_NO_CSPLIT")) else sorted({1, 2, 3, 4, -(-ctiles // 4)})
+        for G in groups:
+            if G > 1 and 4 * -(-ctiles // (4 * G)) * (G - 1) >= ctiles:
+                continue                      # the last group would be empty
             try:
-                t_split, tile_s, ns_split = candidate(gy, 750, 1.0 / gy)
-            except ValueError:          # no tile the fewer, fatter workgroups could prefetch
-                t_split = None
-            if t_split is not None and t_split < 0.8 * t_full:
-                csplit, (ltw, lth, ltn), nslabs = 1, tile_s, ns_split
+                t, tile_g, ns_g = candidate(G)
+            except ValueError:                # no tile the fewer, fatter workgroups could prefetch
+                continue
+            if best is None or t < 0.9 * best[0]:        # a split must pay clearly
+                best = (t, G, tile_g, ns_g)
+        _, G, (ltw, lth, ltn), nslabs = best
+        csplit = G if G > 1 else 0
         # every weight-gradient launch owns its slab (1.2 GB in total for BASELINE config 2 -- 0.4 % of the 288 GB of HBM): no
         # ordering between a launch and the reduction of an earlier one is ever needed
         self.nwgrad = getattr(self, "nwgrad", 0) + 1
