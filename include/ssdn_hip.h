@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSDN_ABI_VERSION 3
+#define SSDN_ABI_VERSION 4
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -125,6 +125,8 @@ typedef struct ssdn_conv_args {
     int32_t ltw, lth, ltn;
     int32_t kc; /* channel chunk staged in LDS at a time (multiple of 16, divides Ktot) */
     int32_t bf16;
+    int32_t kreal; /* real (un-padded) input channels among the Ktot slots: only used for the profiler's algorithmic flop count
+                      (0: = Ktot) */
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -355,6 +357,15 @@ int ssdn_device_cus(void);
 int ssdn_profile_enable(int kind, int max_launches);
 int ssdn_profile_set_stride(int kind, int stride);
 int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* flops, double* bytes);
+
+/* Which kernel serves SSDN_OP_CONV: 0 = k_conv always; 1 (default) = the persistent LDS-DMA kernel k_cdma for 3x3 layers of
+ * its shape class with at least one 256-pixel tile per CU; 2 = k_cdma for every layer of its shape class (test aid). */
+int ssdn_conv_set_mode(int mode);
+
+/* Tuning aid (tools/conv_bench.py): device buffer that receives 32 s_memtime stamps per workgroup of the MFMA kernels, or
+ * NULL (default) for none. */
+void ssdn_debug_set_trace(void* device_buffer);
+void* ssdn_debug_get_trace(void);
 
 /* Hardware probes used by the test-suite (tests/test_hip_probe.py): raw lane mapping of
  * v_mfma_f32_32x32x16_f16 and ds_read_b64_tr_b16 on this device.  out: device buffers. */

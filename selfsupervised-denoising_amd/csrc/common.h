@@ -99,4 +99,9 @@ int launch_mse(const ssdn_mse_args* a, int masked, hipStream_t s);
 int launch_adam(const ssdn_adam_args* a, hipStream_t s);
 int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s);
 int conv_lds_bytes(const ssdn_conv_args* a);
+// conv_dma.hip: persistent LDS-DMA convolution for the 3x3 layers that carry the flops
+bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size);
+int conv_dma_lds_bytes(int mt);
+int launch_conv_dma(const ssdn_conv_args* a, hipStream_t s);
+extern "C" int ssdn_device_cus(void);
 int wgrad_lds_bytes(const ssdn_wgrad_args* a);

@@ -491,6 +491,17 @@ static bool conv_uses_mt1(const ssdn_conv_args* a, const ConvGeom& g) {
     return !a->dst32 && g.tiles_x * g.tiles_y * g.groups_n <= mt1_tiles && a->Mpad >= 64;
 }
 
+// which kernel serves a layer: 0 = always k_conv, 1 = k_cdma where its shape class fits AND the layer has >= 1 tile per CU
+// (default), 2 = k_cdma wherever the shape class fits (lets the test-suite drive it at fixture sizes).  Initial value from
+// the environment (SSDN_CONV_DMA, read once), changed with ssdn_conv_set_mode().
+static int g_conv_mode = [] { const char* e = getenv("SSDN_CONV_DMA"); return e ? atoi(e) : 1; }();
+extern "C" int ssdn_conv_set_mode(int mode) {
+    if (mode < 0 || mode > 2) return ssdn_set_error("conv mode must be 0, 1 or 2");
+    g_conv_mode = mode;
+    return 0;
+}
+static bool conv_use_dma(const ssdn_conv_args* a) { return g_conv_mode > 0 && conv_dma_eligible(a, g_conv_mode == 2); }
+
 static int conv_validate(const ssdn_conv_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("conv: ntaps out of range");
     if (a->ltw + a->lth + a->ltn > 9 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 512 pixels");
@@ -517,6 +528,7 @@ static size_t conv_lds(const ssdn_conv_args* a, const ConvGeom& g, int mt) {
 
 int conv_lds_bytes(const ssdn_conv_args* a) {
     if (conv_validate(a)) return -1;
+    if (conv_use_dma(a)) return conv_dma_lds_bytes(a->Mpad >= 96 ? 3 : a->Mpad / 32);
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     int mt = a->Mpad / 32;
     if (mt > 3) mt = 3;
@@ -539,8 +551,10 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     int m_real = a->M - x.m_base;
     m_real = m_real < 0 ? 0 : (m_real > nblk_y * MT * 32 ? nblk_y * MT * 32 : m_real);
     double px = (double)a->N * a->H * a->W;
-    double flops = 2.0 * px * m_real * a->Ktot * a->ntaps;
-    double bytes = nblk_y * px * (a->Ktot * 2.0 / (a->up0 && a->c1 == 0 ? 4.0 : 1.0)) + px * m_real * (a->dst32 ? 4.0 : 2.0);
+    // algorithmic work: REAL input channels (kreal; padded slots do not count), every input read once, every output written once
+    const int kreal = a->kreal > 0 ? a->kreal : a->Ktot;
+    double flops = 2.0 * px * m_real * kreal * a->ntaps;
+    double bytes = px * (a->c0 * 2.0 / (a->up0 ? 4.0 : 1.0) + a->c1 * 2.0) + px * m_real * (a->dst32 ? 4.0 : 2.0);
     prof_begin(3 - MT, s);
     x.nblk = nblk_y;
     const int grid_all = nblk_y > 1 ? ((grid + 7) / 8) * 8 * nblk_y : grid;
@@ -564,9 +578,11 @@ static int conv_launch_ks(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     return ssdn_set_error("conv: unsupported kc %d", a->kc);
 }
 
+
 int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     int rc = conv_validate(a);
     if (rc) return rc;
+    if (conv_use_dma(a)) return launch_conv_dma(a, s);
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     ConvAux x;
     x.mg_hw = magic_of(g.HW);
@@ -574,11 +590,12 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     x.mg_ntaps = magic_of(a->ntaps);
     x.m_base = 0;
     {
-        const char* e = getenv("SSDN_CONV_ABLATE");
-        x.ablate = e ? atoi(e) : 0;
+        // tuning aids, read ONCE per process (not on the launch path)
+        static const int env_ablate = [] { const char* e = getenv("SSDN_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+        static const int env_desync = [] { const char* e = getenv("SSDN_CONV_DESYNC"); return e ? atoi(e) : 0; }();
+        x.ablate = env_ablate;
         x.trace = g_conv_trace;
-        e = getenv("SSDN_CONV_DESYNC");
-        x.desync = e ? atoi(e) : 0;
+        x.desync = env_desync;
     }
     // output channels in blocks of 96 (MT=3); the tail uses MT = 1 or 2.  Layers with few pixel tiles are latency-bound (one
     // workgroup's pass over its tile IS the launch): they run as blocks of 32 channels (MT=1) on three times as many

@@ -135,6 +135,7 @@ class DeviceNet:
             s.dst32 = _ptr(self.t[a["dst32"]]) if a["dst32"] is not None else None
             s.ltw, s.lth, s.ltn, s.kc = a["ltw"], a["lth"], a["ltn"], a["kc"]
             s.bf16 = a["bf16"]
+            s.kreal = a.get("kreal", 0)
             if L.load().ssdn_conv_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("conv %s/%s: %s" % (a["layer"], a["role"], L.load().ssdn_last_error().decode()))
             return op.type, s

@@ -99,7 +99,7 @@ def net_layers(in_channels: int, out_channels: int, blindspot: bool) -> List[Lay
         Layer("decode_block_3.2", 96, 96, 3, 96, 0, 0),
         Layer("decode_block_2.0", 96, 144, 3, 96, 48, 48),
         Layer("decode_block_2.2", 96, 96, 3, 96, 0, 0),
-        Layer("decode_block_1.0", 96, 96 + c, 3, 96, 2 * cpad, c),      # K = 96 + 32: two channel chunks of 64
+        Layer("decode_block_1.0", 96, 96 + c, 3, 96, cpad, c),          # K = 96 + 16: two 48-channel chunks + a 16-channel tail
         Layer("decode_block_1.2", 96, 96, 3, 96, 0, 0),
         Layer("output_block.0", nin, nin, 1, nin, 0, 0),
         Layer("output_block.2", 96, nin, 1, nin, 0, 0),
@@ -273,7 +273,8 @@ class NetPlan:
         ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None, cus=self.cus)
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                    taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
-                                   dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"))))
+                                   dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"),
+                                   kreal=(layer.cin if role == "fwd" else layer.M))))
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
                m_off=0, c_off=0, with_bias=True, cblocks=None, mblocks=1):
@@ -385,7 +386,7 @@ class NetPlan:
         d4a, d4b = dec("d4a", "d4b", "decode_block_4.0", "decode_block_4.2", d5b, 96, p3, 48, H // 8, W // 8)
         d3a, d3b = dec("d3a", "d3b", "decode_block_3.0", "decode_block_3.2", d4b, 96, p2, 48, H // 4, W // 4)
         d2a, d2b = dec("d2a", "d2b", "decode_block_2.0", "decode_block_2.2", d3b, 96, p1, 48, H // 2, W // 2)
-        d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 32, H, W)
+        d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W)
 
         nin = 384 if bs else 96
         if bs:

@@ -12,11 +12,17 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_header_symbols():
     lib = L.load()
     hdr = open(os.path.join(ROOT, "include", "ssdn_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*)\s+(ssdn_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|const char\*|void\*?)\s+(ssdn_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s), s
-    assert lib.ssdn_abi_version() == L.ABI_VERSION == 3
+    # ... and the other direction: every ssdn_* symbol the library exports is declared in the header
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", L.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("ssdn_") and " T " in ln}
+    assert exported == declared, (exported ^ declared)
+    m = re.search(r"#define SSDN_ABI_VERSION (\d+)", hdr)
+    assert lib.ssdn_abi_version() == L.ABI_VERSION == int(m.group(1))
 
 
 def test_struct_mirrors_match_compiler_layout():

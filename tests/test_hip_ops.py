@@ -122,15 +122,26 @@ def _out_of(op):
 # (cin, cout, blindspot, B, P, cus): cus = 0 plans for the device's CU count; a small value plans persistent grids of that
 # many workgroups, so that the multi-tile paths of the weight-gradient kernel (double-buffered prefetch, compile-time K-step
 # schedule of the hot shapes) run at test sizes too -- at cus = 256 they only trigger from BASELINE config 2 upwards
-CASES = [(3, 9, True, 2, 32, 0), (1, 2, True, 1, 32, 0), (3, 3, False, 2, 32, 0), (3, 9, True, 1, 64, 0), (3, 1, False, 2, 64, 0),
-         (3, 9, True, 8, 32, 0), (3, 9, True, 2, 32, 8), (3, 3, False, 2, 64, 6)]
+# conv_mode (last field): 1 = the library's default kernel choice; 2 = the persistent LDS-DMA kernel k_cdma for every 3x3
+# layer of its shape class (>= 16x16 pixels), which by default only serves layers with >= 1 tile per CU (BASELINE sizes)
+CASES = [(3, 9, True, 2, 32, 0, 1), (1, 2, True, 1, 32, 0, 1), (3, 3, False, 2, 32, 0, 1), (3, 9, True, 1, 64, 0, 1), (3, 1, False, 2, 64, 0, 1),
+         (3, 9, True, 8, 32, 0, 1), (3, 9, True, 2, 32, 8, 1), (3, 3, False, 2, 64, 6, 1),
+         (3, 9, True, 2, 32, 0, 2), (1, 2, True, 1, 32, 0, 2), (3, 3, False, 2, 64, 0, 2), (3, 9, True, 3, 64, 0, 2), (3, 1, False, 5, 32, 0, 2)]
 
 
-@pytest.mark.parametrize("cin,cout,bs,B,P,cus_plan", CASES)
-def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan):
+@pytest.fixture
+def conv_mode_reset():
+    yield
+    from ssdn.hip import lib as L
+    L.load().ssdn_conv_set_mode(1)
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P,cus_plan,conv_mode", CASES)
+def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_mode_reset):
     from ssdn.hip.engine import DeviceNet, OpList, current_stream
     from ssdn.hip.graph import NetPlan
     from ssdn.hip import lib as L
+    L.check(L.load().ssdn_conv_set_mode(conv_mode))
     cus = cus_plan or L.load().ssdn_device_cus()
     p = R.make_params(cin, cout, bs, seed=7)
     plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=cus)
@@ -225,7 +236,7 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan):
             dn.t[dst.t][..., dst.co:dst.co + ch] = ref.to(dev()).to(dn.t[dst.t].dtype)
         i += 1
     os.makedirs(OUTDIR, exist_ok=True)
-    with open(os.path.join(OUTDIR, "teacher_forced_%d_%d_%d_%d_%d_cus%d.txt" % (cin, cout, int(bs), B, P, cus_plan)), "w") as f:
+    with open(os.path.join(OUTDIR, "teacher_forced_%d_%d_%d_%d_%d_cus%d_mode%d.txt" % (cin, cout, int(bs), B, P, cus_plan, conv_mode)), "w") as f:
         f.write("\n".join(failures) if failures else "all %d ops OK\n" % len(ops))
     assert not failures, "\n".join(failures[:40])
 

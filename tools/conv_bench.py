@@ -84,7 +84,7 @@ def all_ops(kind="wgrad"):
         t = time_op(dn, op)
         tot += t
         if kind in ("wgrad", "conv"):
-            flops = 2.0 * a["N"] * a["H"] * a["W"] * a["M"] * a["Ktot"] * len(a["taps"])
+            flops = 2.0 * a["N"] * a["H"] * a["W"] * a["M"] * (a.get("kreal") or a["Ktot"]) * len(a["taps"])   # real channels
             print("%-18s %-5s N=%3d H=%3d K=%3d M=%3d taps=%d tile (%d,%d,%d) : %8.1f us  %7.1f TF" % (
                 a["layer"], a.get("role", kind), a["N"], a["H"], a["Ktot"], a["M"], len(a["taps"]), 1 << a["ltw"], 1 << a["lth"], 1 << a["ltn"],
                 t, flops / t / 1e6))
