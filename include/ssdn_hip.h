@@ -125,6 +125,10 @@ typedef struct ssdn_conv_args {
     int32_t ltw, lth, ltn;
     int32_t kc; /* channel chunk staged in LDS at a time (multiple of 16, divides Ktot) */
     int32_t bf16;
+    const void* wc; /* optional second copy of the weights for the persistent LDS-DMA kernel (k_cdma), or NULL: chunk-major and
+                       pre-swizzled, [tap][chunk][Mpad][kc] with kc = 48 (chunks of 48 input channels, then one optional 16-channel
+                       chunk); the 16-byte piece p of row m is stored at piece p ^ ((m >> 3) & 1) -- exactly the LDS image, so a
+                       (tap, chunk) slice is one linear, fully coalesced DMA (SSDN_OP_WPACK writes it: wfc / wdc) */
     int32_t kreal; /* real (un-padded) input channels among the Ktot slots: only used for the profiler's algorithmic flop count
                       (0: = Ktot) */
 } ssdn_conv_args;
@@ -228,6 +232,8 @@ typedef struct ssdn_wpack_args {
     int32_t c0, c1_real;
     int32_t Mpad_f, Ktot; /* forward shadow dims */
     int32_t Mpad_d, Kd;   /* dgrad shadow dims: Mpad_d >= Ktot, Kd >= M (multiple of 16) */
+    void* wfc;            /* optional chunk-major pre-swizzled copies of wf / wd (see ssdn_conv_args.wc), same sizes; NULL: none. */
+    void* wdc;            /* Only for Ktot (resp. Kd) = 48 n or 48 n + 16 */
 } ssdn_wpack_args;
 
 /* ---- SSDN_OP_GRAD_PACK ----------------------------------------------------------------------

@@ -75,7 +75,9 @@ class Interp:
         out[..., :C] = st
         self.store(dst, cpad, out)
 
-    def op_wpack(self, layer, M, cin, ntaps, c0, c1_real, Mpad_f, Ktot, Mpad_d, Kd, need_d):
+    def op_wpack(self, layer, M, cin, ntaps, c0, c1_real, Mpad_f, Ktot, Mpad_d, Kd, need_d, cm_f=False, cm_d=False):
+        # (cm_f / cm_d: the device also writes chunk-major pre-swizzled copies for k_cdma -- a layout detail of the HIP library,
+        #  checked through the convolutions that read them)
         w, _ = self.weight(layer)                       # [M, cin, ntaps]
         kmap = [k if k < c0 else (c0 + k - c0 if k - c0 < c1_real else -1) for k in range(Ktot)]
         wf = torch.zeros(ntaps, Mpad_f, Ktot)

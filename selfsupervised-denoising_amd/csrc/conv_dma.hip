@@ -42,7 +42,10 @@ struct CdAux {
     int segs, tps;              // a strip (image, tile column) is cut into `segs` work items of `tps` consecutive tiles
     int nitems, xcd_map;
     int nfull, tail16;          // 48-channel chunks, then an optional 16-channel chunk
-    int ablate;                 // tuning aid (env SSDN_CDMA_ABLATE, read once): 1 no MFMA, 2 no weight DMA, 4 no tile DMA, 8 no epilogue
+    int ablate;                 // tuning aid (env SSDN_CDMA_ABLATE, read once): 1 no MFMA, 2 no weight DMA, 4 no tile DMA, 8 no epilogue,
+                                // 16 no DMA waits, 32 no step barriers, 64 DMA fetches nothing (zeros), 128 DMA with
+                                // all lanes masked (16..128: wrong results, timing only)
+    int wrep;                   // experiment (env SSDN_CDMA_WREP): the weight tensor exists in `wrep` consecutive copies
     unsigned long long* trace;  // tuning aid (ssdn_debug_set_trace): s_memtime stamps, 32 per workgroup
 };
 
@@ -61,32 +64,41 @@ __device__ __forceinline__ f32x16 cd_mma(half8 av, half8 bv, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
 }
 
-// one step on the matrix cores: tap (I, J) of a KS*16-channel chunk.  ap = weight slice [MT*32][KS*2 pieces] + lane base,
-// bp = halo tile + lane base (of the tap row's parity).
-template <int MT, bool BF, int KS, int I, int J>
-__device__ __forceinline__ void cd_step(f32x16 (&acc)[MT][2], const char* ap, const char* bp) {
-    constexpr int PSTR = KS * 32;            // bytes per pixel / weight row
-    constexpr int PITCH = 18 * PSTR;         // bytes per halo row
-    constexpr int BOFF = I * PITCH + J * PSTR;
-    half8 bq[2][2], aq[2][MT];
-    bq[0][0] = *reinterpret_cast<const half8*>(bp + BOFF);
-    bq[0][1] = *reinterpret_cast<const half8*>(bp + BOFF + 2 * PITCH);
+// ---- one step on the matrix cores: tap (I, J) of a KS*16-channel chunk ---------------------------------------------------------
+// The LDS -> register -> MFMA pipeline is written by hand: left to itself the compiler (which aims at minimum register pressure
+// here) re-uses ONE fragment register set and waits for every ds_read right after issuing it -- nine exposed LDS round trips per
+// step.  The fragment reads are inline asm (the compiler neither reorders volatile asm statements nor knows that their results
+// arrive late), the wait is an asm statement that takes every fragment register as a read-write operand (so no consumer can be
+// scheduled above it), and sched_barrier pins the reads of K-step k+1 in front of the MFMAs of K-step k.
+template <int OFF>
+__device__ __forceinline__ void lds_rd128(half8& dst, unsigned addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "i"(OFF));
+}
+template <int MT>
+__device__ __forceinline__ void lds_wait0(half8 (&aq)[MT], half8 (&bq)[2]) {
+    if constexpr (MT == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aq[0]), "+v"(aq[1]), "+v"(aq[2]), "+v"(bq[0]), "+v"(bq[1]));
+    else if constexpr (MT == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aq[0]), "+v"(aq[1]), "+v"(bq[0]), "+v"(bq[1]));
+    else
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(aq[0]), "+v"(bq[0]), "+v"(bq[1]));
+}
+// fragment reads of K-step KS_ of tap (I, J): ap = LDS address of the weight slice + lane base, bp = of the halo tile + lane base
+template <int MT, int KS, int I, int J, int KS_>
+__device__ __forceinline__ void cd_reads(half8 (&aq)[MT], half8 (&bq)[2], unsigned ap, unsigned bp) {
+    constexpr int PSTR = KS * 32, PITCH = 18 * PSTR, BOFF = I * PITCH + J * PSTR;
+    lds_rd128<BOFF + KS_ * 32>(bq[0], bp);
+    lds_rd128<0 * 32 * PSTR + KS_ * 32>(aq[0], ap);
+    lds_rd128<BOFF + 2 * PITCH + KS_ * 32>(bq[1], bp);
+    if constexpr (MT > 1) lds_rd128<1 * 32 * PSTR + KS_ * 32>(aq[1], ap);
+    if constexpr (MT > 2) lds_rd128<2 * 32 * PSTR + KS_ * 32>(aq[2], ap);
+}
+template <int MT, bool BF>
+__device__ __forceinline__ void cd_mmas(f32x16 (&acc)[MT][2], const half8 (&aq)[MT], const half8 (&bq)[2]) {
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) aq[0][mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * PSTR);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-        const int cur = ks & 1, nxt = cur ^ 1;
-        if (ks + 1 < KS) {
-            bq[nxt][0] = *reinterpret_cast<const half8*>(bp + BOFF + (ks + 1) * 32);
-            bq[nxt][1] = *reinterpret_cast<const half8*>(bp + BOFF + 2 * PITCH + (ks + 1) * 32);
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) aq[nxt][mt] = *reinterpret_cast<const half8*>(ap + mt * 32 * PSTR + (ks + 1) * 32);
-        }
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            acc[mt][0] = cd_mma<BF>(aq[cur][mt], bq[cur][0], acc[mt][0]);
-            acc[mt][1] = cd_mma<BF>(aq[cur][mt], bq[cur][1], acc[mt][1]);
-        }
+    for (int mt = 0; mt < MT; ++mt) {
+        acc[mt][0] = cd_mma<BF>(aq[mt], bq[0], acc[mt][0]);
+        acc[mt][1] = cd_mma<BF>(aq[mt], bq[1], acc[mt][1]);
     }
 }
 
@@ -110,7 +122,6 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     const int lw = w & 1;                     // index inside the role
     const unsigned lds0 = (unsigned)(size_t)smem;
     char* const tbuf0 = smem;
-    char* const wbuf0 = smem + 2 * CD_TBYTES;
     const unsigned tlds0 = lds0, wlds0 = lds0 + 2 * CD_TBYTES;
 
     // ---- work items of this workgroup ---------------------------------------------------------------------------------
@@ -167,8 +178,10 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // ---- buffer resources ---------------------------------------------------------------------------------------------------
     // (num_records = 2 GiB for every resource: all tensors are smaller -- checked by the launcher -- and the one out-of-range
     //  offset used, 0x80000000, still reads as zero; constants cost no live SGPRs)
-    const unsigned long long wp = (unsigned long long)a.w;
+    const unsigned long long wp = (unsigned long long)a.w + (x.wrep > 1 ? (unsigned long long)((blockIdx.x >> 3) % x.wrep) * (9ull * a.Mpad * a.Ktot * 2) : 0ull);
     const u32x4_t rs_w = {(unsigned)wp, (unsigned)(wp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const unsigned long long wcp = (unsigned long long)a.wc;
+    const u32x4_t rs_wc = {(unsigned)wcp, (unsigned)(wcp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
     const unsigned long long p0 = (unsigned long long)a.src0.p, p1 = (unsigned long long)a.src1.p;
     const u32x4_t rs_s0 = {(unsigned)p0, (unsigned)(p0 >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
@@ -183,12 +196,25 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     auto issue_w = [&](int c, int tseq, int wpar) __attribute__((always_inline)) {
         if (x.ablate & 2) return;
         const int tw = x.rev ? 8 - tseq : tseq;
-        const int soff = ((tw * a.Mpad + x.m_base) * a.Ktot + c * 48) * 2;
         const unsigned dst = wlds0 + wpar * WBYTES;
+        if (a.wc) {
+            // chunk-major pre-swizzled copy [tap][chunk][Mpad][kc]: the slice IS the LDS image -> linear 1 KiB pieces
+            const bool full = c < x.nfull;
+            const int sbase = ((tw * a.Mpad * a.Ktot) + c * 48 * a.Mpad + x.m_base * (full ? 48 : 16)) * 2;
+            const int nq = full ? NWQ : MT;
+#pragma unroll
+            for (int u = 0; u < NWU; ++u)
+                if (lw + 2 * u < nq) dma16(dst + (lw + 2 * u) * 1024, lane * 16, rs_wc, sbase + (lw + 2 * u) * 1024);
+            return;
+        }
+        const int soff = ((tw * a.Mpad + x.m_base) * a.Ktot + c * 48) * 2;
         if (c < x.nfull) {
 #pragma unroll
             for (int u = 0; u < NWU; ++u)
-                if (lw + 2 * u < NWQ) dma16(dst + (lw + 2 * u) * 1024, wv48[u], rs_w, soff);
+                if (lw + 2 * u < NWQ) {
+                    if (x.ablate & 128) { if (lane > 64) dma16(dst + (lw + 2 * u) * 1024, wv48[u], rs_w, soff); }
+                    else dma16(dst + (lw + 2 * u) * 1024, (x.ablate & 64) ? (int)0x80000000 : wv48[u], rs_w, soff);
+                }
         } else {
 #pragma unroll
             for (int u = 0; u < NWU16; ++u)
@@ -197,12 +223,29 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     };
     // waves 2-3: DMA of halo-tile ROWS.  A row of a 48-channel chunk is 18 pixels x 6 pieces = 108 pieces = two instructions of
     // 54 active lanes (the other 10 are EXEC-masked: masked lanes write nothing); a row of the 16-channel chunk is 36 pieces =
-    // one instruction.  Everything about a ROW is wave-uniform (image row, validity, base address -> SGPRs); per lane only the
-    // (pixel, piece) -> byte offset inside the row remains, the same for every row: ~3 VALU per instruction.
+    // one instruction.  Everything about a ROW is wave-uniform (image row, validity, base address -> SGPRs / soffset); per lane
+    // only the (pixel, piece) -> byte offset inside the row remains, the same for every row of a (tile, chunk) up to the
+    // swizzle's row parity: prepared once per chunk (row_lane), so a row item costs ~10 scalar and 1 vector
+    // instruction.  (First version: ~60 instructions per item, which made the tile waves the slow ones at every barrier.)
     // row item r of a chunk: 48-ch: halo row r >> 1, half r & 1 (36 items); 16-ch: halo row r (18 items).  Wave lw takes r = lw + 2u.
-    // LDS piece p of a row holds (pixel p / PP, channel piece (p % PP) ^ (hy & 1)): the swizzle is applied on the SOURCE side by
-    // flipping the lowest piece bit of the lane's source offset for odd rows.
-    auto issue_rows = [&](const CdTile& t, int c, int tpar, int u0, int nu) __attribute__((always_inline)) {
+    // LDS piece p of a row holds (pixel p / PP, channel piece (p % PP) ^ (hy & 1)): the swizzle is applied on the SOURCE side.
+    // byte offset of this lane's 16 bytes inside a source row of (tile t, chunk c), for an even (pr = 0) / odd halo row, or OOB.
+    // (A wave always fetches the same half of the 48-channel rows: half = lw.)
+    auto row_lane = [&](const CdTile& t, int c, int pr) __attribute__((always_inline)) {
+        const int k0 = c * 48;
+        const bool from0 = k0 < a.c0;
+        const bool up = from0 && a.up0;
+        const int cs = from0 ? a.src0.cs : a.src1.cs;
+        const bool full = c < x.nfull;
+        const int hp48 = lane / 6;
+        const int hx = full ? hp48 + 9 * lw : lane >> 1;
+        const int cc = full ? lane - hp48 * 6 : lane & 1;
+        const int xx = t.x0 - x.padL + hx;
+        const bool ok = (unsigned)xx < (unsigned)a.W;
+        const int xs = up ? xx >> 1 : xx;
+        return ok ? (xs * cs + (cc ^ pr) * 8) * 2 : (int)0x80000000;
+    };
+    auto issue_rows = [&](const CdTile& t, int c, int tpar, int rlE, int rlO, int u0, int nu) __attribute__((always_inline)) {
         if (x.ablate & 4) return;
         const int k0 = c * 48;
         const bool from0 = k0 < a.c0;
@@ -211,9 +254,10 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         const int cs = from0 ? a.src0.cs : a.src1.cs;
         const int cbase = from0 ? a.src0.co + k0 : a.src1.co + k0 - a.c0;
         const int Hs = up ? H0 : a.H, Ws = up ? W0 : a.W;
-        const int yb = t.y0 - x.padT, xb = t.x0 - x.padL;
+        const int yb = t.y0 - x.padT;
         const unsigned dst = tlds0 + tpar * CD_TBYTES;
         const bool full = c < x.nfull;
+        const bool act = full ? lane < 54 : lane < 36;
 #pragma unroll
         for (int uu = 0; uu < 18; ++uu) {
             if (uu >= nu) break;               // (nu is a constant at every call site: the loop unrolls to nu items)
@@ -223,18 +267,11 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             const int y = yb + hy;
             const bool rowok = (unsigned)y < (unsigned)a.H;
             const int ys = up ? y >> 1 : y;
-            // lane -> pixel / piece of this instruction (half 0: pieces 0..53 -> pixels 0..8; half 1: pixels 9..17)
-            const int hp48 = lane / 6;
-            const int hx = full ? hp48 + 9 * half : lane >> 1;
-            const int cc = (full ? lane - hp48 * 6 : lane & 1) ^ (hy & 1);
-            const bool act = full ? lane < 54 : lane < 36;
-            const int xx = xb + hx;
-            const bool ok = rowok && (unsigned)xx < (unsigned)a.W;
-            const int xs = up ? xx >> 1 : xx;
-            const int rowoff = ((t.n * Hs + ys) * Ws) * cs + cbase;                    // scalar
-            const int voff = ok ? (rowoff + xs * cs + cc * 8) * 2 : (int)0x80000000;
+            const int soff = __builtin_amdgcn_readfirstlane(rowok ? (((t.n * Hs + ys) * Ws) * cs + cbase) * 2 : 0);      // wave-uniform
+            const int voff = rowok ? ((hy & 1) ? rlO : rlE) : (int)0x80000000;
             const unsigned ldsrow = dst + hy * (full ? 1728 : 576) + half * 864;
-            if (act) dma16(ldsrow, voff, rs, 0);
+            if (x.ablate & 128) { if (lane > 64) dma16(ldsrow, voff, rs, soff); }
+            else if (act) dma16(ldsrow, (x.ablate & 64) ? (int)0x80000000 : voff, rs, soff);
         }
     };
 
@@ -255,7 +292,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     float* const bl = reinterpret_cast<float*>(smem + 18 * 18 * 96);
     if (tid < WROWS) bl[tid] = (a.bias && tid < x.m_cnt) ? a.bias[x.m_base + tid] : 0.f;
     if (wload) issue_w(0, 0, 0);
-    else issue_rows(cur, 0, 0, 0, 18);
+    else issue_rows(cur, 0, 0, row_lane(cur, 0, 0), row_lane(cur, 0, 1), 0, 18);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -290,41 +327,64 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             CdTile pt;                                           // (by value: a reference picked at run time would put both tiles in scratch)
             pt.n = last_chunk ? nxt.n : cur.n; pt.y0 = last_chunk ? nxt.y0 : cur.y0; pt.x0 = last_chunk ? nxt.x0 : cur.x0;
             const bool pf_full = pc < x.nfull;
-            const char* tb = tbuf0 + tpar * CD_TBYTES;
+            int rlE = 0, rlO = 0;
+            if (!wload && pf) { rlE = row_lane(pt, pc, 0); rlO = row_lane(pt, pc, 1); }
             // step head: the loaders start the fetches that must have landed one step (weights) / one chunk (tile) from now
             auto step_head = [&](int t) __attribute__((always_inline)) {
                 if (wload) {
                     if (t < 8) issue_w(c, t + 1, wpar ^ 1);
                     else if (pf) issue_w(pc, 0, wpar ^ 1);
                 } else if (pf && t < 8) {
-                    if (pf_full) issue_rows(pt, pc, tpar ^ 1, t < 2 ? 3 * t : 2 * t + 2, t < 2 ? 3 : 2);   // 18 row items per wave over steps 0..7
-                    else issue_rows(pt, pc, tpar ^ 1, t < 1 ? 0 : t + 1, t < 1 ? 2 : 1);                    // 9 row items per wave
+                    if (pf_full) issue_rows(pt, pc, tpar ^ 1, rlE, rlO, t < 2 ? 3 * t : 2 * t + 2, t < 2 ? 3 : 2);   // 18 row items per wave over steps 0..7
+                    else issue_rows(pt, pc, tpar ^ 1, rlE, rlO, t < 1 ? 0 : t + 1, t < 1 ? 2 : 1);                    // 9 row items per wave
                 }
             };
             // step tail: own DMA landed, then ONE barrier: every wave's DMA landed and every wave is done with this step's buffers
             auto step_tail = [&](int t) __attribute__((always_inline)) {
-                if (wload || t == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
+                if ((wload || t == 8) && !(x.ablate & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!(x.ablate & 32)) __builtin_amdgcn_s_barrier();
                 wpar ^= 1;
             };
             if (c < x.nfull) {
-                const char* bE = tb + bE48;
-                const char* bO = tb + bO48;
+                const unsigned bE = tlds0 + tpar * CD_TBYTES + bE48, bO = tlds0 + tpar * CD_TBYTES + bO48;
 #define CD_STEP48(T, I, J)                                                  \
-    step_head(T);                                                           \
-    if (!(x.ablate & 1)) cd_step<MT, BF, 3, I, J>(acc, wbuf0 + wpar * WBYTES + aB48, (I & 1) ? bO : bE); \
-    step_tail(T);
+    {                                                                       \
+        const unsigned ap = wlds0 + wpar * WBYTES + aB48, bp = (I & 1) ? bO : bE; \
+        half8 aq0[MT], bq0[2], aq1[MT], bq1[2];                             \
+        cd_reads<MT, 3, I, J, 0>(aq0, bq0, ap, bp);                         \
+        step_head(T);                 /* the loaders' DMA issue covers the latency of the first fragment reads */ \
+        lds_wait0<MT>(aq0, bq0);                                            \
+        cd_reads<MT, 3, I, J, 1>(aq1, bq1, ap, bp);                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        if (!(x.ablate & 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        lds_wait0<MT>(aq1, bq1);                                            \
+        cd_reads<MT, 3, I, J, 2>(aq0, bq0, ap, bp);                         \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        if (!(x.ablate & 1)) cd_mmas<MT, BF>(acc, aq1, bq1);                \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        lds_wait0<MT>(aq0, bq0);                                            \
+        if (!(x.ablate & 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        step_tail(T);                                                       \
+    }
                 CD_STEP48(0, 0, 0) CD_STEP48(1, 0, 1) CD_STEP48(2, 0, 2)
                 CD_STEP48(3, 1, 0) CD_STEP48(4, 1, 1) CD_STEP48(5, 1, 2)
                 CD_STEP48(6, 2, 0) CD_STEP48(7, 2, 1) CD_STEP48(8, 2, 2)
 #undef CD_STEP48
             } else {
-                const char* bE = tb + bE16;
-                const char* bO = tb + bO16;
+                const unsigned bE = tlds0 + tpar * CD_TBYTES + bE16, bO = tlds0 + tpar * CD_TBYTES + bO16;
 #define CD_STEP16(T, I, J)                                                  \
-    step_head(T);                                                           \
-    cd_step<MT, BF, 1, I, J>(acc, wbuf0 + wpar * WBYTES + aB16, (I & 1) ? bO : bE); \
-    step_tail(T);
+    {                                                                       \
+        const unsigned ap = wlds0 + wpar * WBYTES + aB16, bp = (I & 1) ? bO : bE; \
+        half8 aq0[MT], bq0[2];                                              \
+        cd_reads<MT, 1, I, J, 0>(aq0, bq0, ap, bp);                         \
+        step_head(T);                                                       \
+        lds_wait0<MT>(aq0, bq0);                                            \
+        cd_mmas<MT, BF>(acc, aq0, bq0);                                     \
+        __builtin_amdgcn_sched_barrier(0);                                  \
+        step_tail(T);                                                       \
+    }
                 CD_STEP16(0, 0, 0) CD_STEP16(1, 0, 1) CD_STEP16(2, 0, 2)
                 CD_STEP16(3, 1, 0) CD_STEP16(4, 1, 1) CD_STEP16(5, 1, 2)
                 CD_STEP16(6, 2, 0) CD_STEP16(7, 2, 1) CD_STEP16(8, 2, 2)
@@ -515,6 +575,8 @@ int launch_conv_dma(const ssdn_conv_args* a, hipStream_t s) {
     x.nfull = a->Ktot / 48; x.tail16 = (a->Ktot % 48) ? 1 : 0;
     static const int env_ablate = [] { const char* e = getenv("SSDN_CDMA_ABLATE"); return e ? atoi(e) : 0; }();
     x.ablate = env_ablate;
+    static const int env_wrep = [] { const char* e = getenv("SSDN_CDMA_WREP"); return e ? atoi(e) : 0; }();
+    x.wrep = env_wrep;
     x.trace = (unsigned long long*)ssdn_debug_get_trace();
     int rc = 0;
     for (int mb = 0; mb < a->Mpad && !rc; mb += 96) {

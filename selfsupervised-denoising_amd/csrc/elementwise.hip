@@ -298,6 +298,14 @@ static __device__ __forceinline__ int k_to_cin(int k, int c0, int c1_real) {
     int r = k - c0;
     return r < c1_real ? c0 + r : -1;
 }
+// position of element (tap t, row m, column k) in the chunk-major pre-swizzled copy [tap][chunk][rows][kc] (ssdn_conv_args.wc)
+static __device__ __forceinline__ long long wpack_cm(int t, int m, int k, int rows, int K) {
+    const int nfull = K / 48;
+    const int c = k / 48 < nfull ? k / 48 : nfull;
+    const int kk = k - c * 48, kcw = c < nfull ? 48 : 16;
+    const int piece = (kk >> 3) ^ ((m >> 3) & 1);
+    return (long long)t * rows * K + (long long)c * 48 * rows + (long long)m * kcw + piece * 8 + (kk & 7);
+}
 static __device__ __forceinline__ void wpack_element(const ssdn_wpack_args& a, long long idx) {
     long long nf = (long long)a.ntaps * a.Mpad_f * a.Ktot;
     long long nd = a.wd ? (long long)a.ntaps * a.Mpad_d * a.Kd : 0;
@@ -308,6 +316,7 @@ static __device__ __forceinline__ void wpack_element(const ssdn_wpack_args& a, l
         int ci = k_to_cin(k, a.c0, a.c1_real);
         float v = (m < a.M && ci >= 0) ? a.w[((long long)m * a.cin + ci) * a.ntaps + t] : 0.f;
         ((h16*)a.wf)[idx] = (h16)v;
+        if (a.wfc) ((h16*)a.wfc)[wpack_cm(t, m, k, a.Mpad_f, a.Ktot)] = (h16)v;
     } else if (idx < nf + nd) {
         long long e = idx - nf;
         int m = e % a.Kd;                       // reduction index of the dgrad GEMM = forward output channel
@@ -316,6 +325,7 @@ static __device__ __forceinline__ void wpack_element(const ssdn_wpack_args& a, l
         int ci = c < a.Ktot ? k_to_cin(c, a.c0, a.c1_real) : -1;
         float v = (m < a.M && ci >= 0) ? a.w[((long long)m * a.cin + ci) * a.ntaps + t] : 0.f;
         ((unsigned short*)a.wd)[e] = f2bf(v);   // data-gradient shadow is bf16 (gradients are bf16)
+        if (a.wdc) ((unsigned short*)a.wdc)[wpack_cm(t, c, m, a.Mpad_d, a.Kd)] = f2bf(v);
     }
 }
 static inline long long wpack_count(const ssdn_wpack_args* a) {

@@ -128,6 +128,8 @@ class DeviceNet:
             for i, (dy, dx) in enumerate(a["taps"]):
                 s.dy[i], s.dx[i] = dy, dx
             s.w = _ptr(self.t[P + ("wf/" if a["role"] == "fwd" else "wd/") + a["layer"]])
+            wc = self.t.get(P + ("wfc/" if a["role"] == "fwd" else "wdc/") + a["layer"])
+            s.wc = _ptr(wc) if wc is not None else None
             s.M, s.Mpad, s.Ktot = a["M"], a["Mpad"], a["Ktot"]
             s.bias = self._pp(l.b_off) if a["bias"] else None
             s.act = a["act"]
@@ -178,7 +180,9 @@ class DeviceNet:
             l = self._layer(a["layer"])
             return op.type, L.WpackArgs(self._pp(l.w_off), _ptr(self.t[P + "wf/" + l.name]),
                                         _ptr(self.t[P + "wd/" + l.name]) if a["need_d"] else None, a["M"], a["cin"], a["ntaps"],
-                                        a["c0"], a["c1_real"], a["Mpad_f"], a["Ktot"], a["Mpad_d"], a["Kd"])
+                                        a["c0"], a["c1_real"], a["Mpad_f"], a["Ktot"], a["Mpad_d"], a["Kd"],
+                                        _ptr(self.t[P + "wfc/" + l.name]) if a.get("cm_f") else None,
+                                        _ptr(self.t[P + "wdc/" + l.name]) if a.get("cm_d") else None)
         if op.type == "grad_pack":
             return op.type, L.GradPackArgs(_ptr(self.t[a["g"]]), self._view(a["dst"]), a["N"], a["C"], a["H"], a["W"], a["cpad"],
                                            _ptr(self.t[P + "gmax"]), _ptr(self.t[P + "scale"]))

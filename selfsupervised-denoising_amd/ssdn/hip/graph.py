@@ -413,8 +413,17 @@ class NetPlan:
             self.T("wf/" + l.name, "f16", (l.ntaps * l.Mpad_f * l.Ktot,))
             if need_d:
                 self.T("wd/" + l.name, "bf16", (l.ntaps * Mpad_d * l.Kd,))
+            # chunk-major pre-swizzled copies for the persistent LDS-DMA convolution (3x3 layers whose reduction length is
+            # 48 n or 48 n + 16): see ssdn_conv_args.wc
+            cm_f = l.ntaps == 9 and l.Ktot % 48 in (0, 16)
+            cm_d = need_d and l.ntaps == 9 and l.Kd % 48 in (0, 16)
+            if cm_f:
+                self.T("wfc/" + l.name, "f16", (l.ntaps * l.Mpad_f * l.Ktot,))
+            if cm_d:
+                self.T("wdc/" + l.name, "bf16", (l.ntaps * Mpad_d * l.Kd,))
             self.pack.append(Op("wpack", dict(layer=l.name, M=l.M, cin=l.cin, ntaps=l.ntaps, c0=l.c0, c1_real=l.c1_real,
-                                              Mpad_f=l.Mpad_f, Ktot=l.Ktot, Mpad_d=Mpad_d, Kd=l.Kd, need_d=need_d)))
+                                              Mpad_f=l.Mpad_f, Ktot=l.Ktot, Mpad_d=Mpad_d, Kd=l.Kd, need_d=need_d,
+                                              cm_f=cm_f, cm_d=cm_d)))
         if not self.train:
             return
 

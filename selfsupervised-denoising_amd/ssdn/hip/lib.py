@@ -36,7 +36,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32), ("H", i32), ("W", i32),
                 ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("w", vp), ("M", i32), ("Mpad", i32),
                 ("Ktot", i32), ("bias", vp), ("act", i32), ("mask", View), ("add", View), ("dst", View), ("dst32", vp),
-                ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32), ("bf16", i32), ("kreal", i32)]
+                ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32), ("bf16", i32), ("wc", vp), ("kreal", i32)]
 
 
 class PoolArgs(C.Structure):
@@ -67,7 +67,7 @@ class WreduceArgs(C.Structure):
 
 class WpackArgs(C.Structure):
     _fields_ = [("w", vp), ("wf", vp), ("wd", vp), ("M", i32), ("cin", i32), ("ntaps", i32), ("c0", i32), ("c1_real", i32),
-                ("Mpad_f", i32), ("Ktot", i32), ("Mpad_d", i32), ("Kd", i32)]
+                ("Mpad_f", i32), ("Ktot", i32), ("Mpad_d", i32), ("Kd", i32), ("wfc", vp), ("wdc", vp)]
 
 
 class GradPackArgs(C.Structure):

@@ -37,6 +37,11 @@ def main():
             t.copy_(torch.randn(t.shape, device=dev) * 0.5)
     dn.pack.run(current_stream())
     want = sys.argv[1:] or ["decode_block_1.2", "decode_block_2.2", "output_block.0", "encode_block_1.2", "decode_block_5.0"]
+    wrep = int(os.environ.get("SSDN_CDMA_WREP", "0"))
+    if wrep > 1:      # experiment: every packed weight tensor in `wrep` consecutive copies
+        for name in list(dn.t):
+            if "/wf/" in name or "/wd/" in name:
+                dn.t[name] = dn.t[name].repeat(wrep).contiguous()
     for op in plan.fwd + plan.bwd:
         if op.type != "conv" or op.a["layer"] not in want:
             continue
