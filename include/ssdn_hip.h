@@ -60,7 +60,9 @@ enum ssdn_op_type {
     SSDN_OP_MASK_MSE = 16,
     SSDN_OP_ADAM = 17,
     SSDN_OP_SQERR = 18,
-    SSDN_OP_ZERO = 19
+    SSDN_OP_ZERO = 19,
+    SSDN_OP_EVENT_RECORD = 20 /* hipEventRecord(event) on the op's lane: lets a consumer outside the list (the gradient
+                                 all-reduce on its own stream) wait for a PREFIX of the list */
 };
 
 /* One record of the op list.  `args` points at the matching ssdn_*_args struct (host memory).
@@ -333,6 +335,15 @@ typedef struct ssdn_zero_args {
     void* p;
     int64_t bytes;
 } ssdn_zero_args;
+
+/* ---- SSDN_OP_EVENT_RECORD -------------------------------------------------------------------
+ * Records the caller-owned hipEvent_t `event` on the stream of the op's lane, i.e. after every earlier op of that lane (and,
+ * through the lane dependencies, after the lane-0 ops those depend on).  Data parallelism (replaces nn.DataParallel's
+ * reduce, denoiser.py:102-110): the host puts one after the last weight-gradient reduction of each gradient bucket and lets
+ * the RCCL stream wait for it, so a bucket's all-reduce overlaps the rest of the backward pass. */
+typedef struct ssdn_event_args {
+    void* event;
+} ssdn_event_args;
 
 /* Execute `n` ops in order on `stream`.  Returns 0 or a negative error (ssdn_last_error()). */
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream);

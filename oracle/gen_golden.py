@@ -169,7 +169,7 @@ def main():
             npar = 25 / 255.0 if style.startswith("gauss") else 30.0
             noisy = torch.clamp(clean + (R.hash_tensor((Bn, ch, P, P), 62, -1, 1)) * 0.17, 0, 1)
             refimg = clean if alg != "n2v" else torch.clamp(clean + R.hash_tensor((Bn, ch, P, P), 63, -1, 1) * 0.17, 0, 1)
-            coords = R.hash_tensor((Bn, 16, 2), 64, 0, P).long()
+            coords = R.hash_tensor((Bn, 64, 2), 64, 0, P).long()      # 64 coordinates per patch, like the reference sampler (n2v_ups.py:65-88)
             meta = {MD.INPUT_NOISE_VALUES: torch.full((Bn, 1, 1, 1), npar), MD.IMAGE_SHAPE: None, MD.CLEAN: clean}
             if alg == "n2v":
                 meta[MD.MASK_COORDS] = coords

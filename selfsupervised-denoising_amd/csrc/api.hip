@@ -85,6 +85,7 @@ int ssdn_struct_size(int op_type) {
         case SSDN_OP_ADAM: return (int)sizeof(ssdn_adam_args);
         case SSDN_OP_SQERR: return (int)sizeof(ssdn_sqerr_args);
         case SSDN_OP_ZERO: return (int)sizeof(ssdn_zero_args);
+        case SSDN_OP_EVENT_RECORD: return (int)sizeof(ssdn_event_args);
         default: return -1;
     }
 }
@@ -138,16 +139,27 @@ int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a) { return wgrad_lds_bytes(a); 
 
 #define SSDN_NEVENTS 256
 #define SSDN_NLANES 4
-static hipStream_t g_side[SSDN_NLANES] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused (= caller's stream)
-static hipEvent_t g_ev[SSDN_NEVENTS];
-static int g_ev_next = 0;
-static bool g_lanes_ready = false;
-static int lanes_init() {
-    if (g_lanes_ready) return 0;
-    for (int l = 1; l < SSDN_NLANES; ++l) SSDN_CHECK_HIP(hipStreamCreateWithFlags(&g_side[l], hipStreamNonBlocking));
-    for (int i = 0; i < SSDN_NEVENTS; ++i) SSDN_CHECK_HIP(hipEventCreateWithFlags(&g_ev[i], hipEventDisableTiming));
-    g_lanes_ready = true;
-    return 0;
+#define SSDN_MAX_DEVICES 16
+// side streams and dependency events belong to ONE device: one set per device ordinal, created on first use while that
+// device is current (a process normally drives a single GPU, but nothing here assumes it)
+struct LaneSet {
+    hipStream_t side[SSDN_NLANES] = {nullptr, nullptr, nullptr, nullptr};   // [0] unused (= caller's stream)
+    hipEvent_t ev[SSDN_NEVENTS];
+    int ev_next = 0;
+    bool ready = false;
+};
+static LaneSet g_lanesets[SSDN_MAX_DEVICES];
+static LaneSet* lanes_get() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= SSDN_MAX_DEVICES) { ssdn_set_error("lanes: bad current device"); return nullptr; }
+    LaneSet& L = g_lanesets[dev];
+    if (L.ready) return &L;
+    for (int l = 1; l < SSDN_NLANES; ++l)
+        if (hipStreamCreateWithFlags(&L.side[l], hipStreamNonBlocking) != hipSuccess) { ssdn_set_error("lanes: hipStreamCreate failed"); return nullptr; }
+    for (int i = 0; i < SSDN_NEVENTS; ++i)
+        if (hipEventCreateWithFlags(&L.ev[i], hipEventDisableTiming) != hipSuccess) { ssdn_set_error("lanes: hipEventCreate failed"); return nullptr; }
+    L.ready = true;
+    return &L;
 }
 // lanes a lane is ordered after (bit l = lane l): see ssdn_op in the header
 static const unsigned g_lane_deps[SSDN_NLANES] = {0u, 1u << 0, (1u << 0) | (1u << 1) | (1u << 3), 1u << 0};
@@ -158,6 +170,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     bool dirty[SSDN_NLANES][SSDN_NLANES] = {}, used[SSDN_NLANES] = {true, false, false, false};
     for (int d = 1; d < SSDN_NLANES; ++d) dirty[0][d] = true;   // whatever the caller enqueued before this list
     static const bool one_lane = getenv("SSDN_ONE_LANE") != nullptr;   // tuning / debugging aid
+    LaneSet* LS = nullptr;
     for (int i = 0; i < n; ++i) {
         const void* p = ops[i].args;
         int rc = 0;
@@ -165,11 +178,11 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
         int lane = one_lane ? 0 : ops[i].lane;
         if (lane < 0 || lane >= SSDN_NLANES) return ssdn_set_error("op %d: bad lane %d", i, lane);
         if (lane > 0) {
-            if (lanes_init()) return -1;
-            for (int l = 1; l < SSDN_NLANES; ++l) lane_s[l] = g_side[l];
+            if (!LS && !(LS = lanes_get())) return -1;
+            for (int l = 1; l < SSDN_NLANES; ++l) lane_s[l] = LS->side[l];
             for (int src = 0; src < SSDN_NLANES; ++src) {
                 if (!((g_lane_deps[lane] >> src) & 1) || !dirty[src][lane]) continue;
-                hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
+                hipEvent_t e = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
                 SSDN_CHECK_HIP(hipEventRecord(e, lane_s[src]));
                 SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[lane], e, 0));
                 dirty[src][lane] = false;
@@ -215,6 +228,12 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
                 if (g > 0) hipLaunchKernelGGL(k_zero, dim3(g), dim3(256), 0, s, (uint4*)z->p, n16);
                 break;
             }
+            case SSDN_OP_EVENT_RECORD: {
+                const ssdn_event_args* e = (const ssdn_event_args*)p;
+                if (!e->event) return ssdn_set_error("op %d: null event", i);
+                SSDN_CHECK_HIP(hipEventRecord((hipEvent_t)e->event, s));
+                break;
+            }
             default: return ssdn_set_error("op %d: unknown type %d", i, ops[i].type);
         }
         if (rc) {
@@ -225,7 +244,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     }
     for (int l = 1; l < SSDN_NLANES; ++l) {   // join every side lane back into the caller's stream
         if (!used[l]) continue;
-        hipEvent_t e = g_ev[g_ev_next++ % SSDN_NEVENTS];
+        hipEvent_t e = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
         SSDN_CHECK_HIP(hipEventRecord(e, lane_s[l]));
         SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[0], e, 0));
     }

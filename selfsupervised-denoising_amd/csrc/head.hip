@@ -282,6 +282,7 @@ __global__ void k_mask_mse(ssdn_mse_args a) {
     for (int c = threadIdx.x; c < a.C; c += HB) {
         for (int q = 0; q < a.ncoords; ++q) {
             long long r = a.coords[2 * q], cc = a.coords[2 * q + 1];
+            if (r < 0 || r >= a.H || cc < 0 || cc >= a.W) continue;   // (the host validates; never touch memory outside the image)
             long long off = ((long long)b * a.C + c) * HW + r * a.W + cc;
             float d = a.out[off] - a.ref[off];
             acc += d * d;
@@ -295,6 +296,7 @@ __global__ void k_mask_mse(ssdn_mse_args a) {
         for (int c = threadIdx.x; c < a.C; c += HB)
             for (int q = 0; q < a.ncoords; ++q) {
                 long long r = a.coords[2 * q], cc = a.coords[2 * q + 1];
+                if (r < 0 || r >= a.H || cc < 0 || cc >= a.W) continue;
                 gabs = fmaxf(gabs, fabsf(a.g[((long long)b * a.C + c) * HW + r * a.W + cc]));
             }
         atomic_max_abs(a.gmax, gabs);

@@ -21,6 +21,12 @@ from ssdn.models import NoiseNetwork
 from ssdn.params import ConfigValue, NoiseValue, Pipeline, PipelineOutput
 
 
+import os as _os
+
+_CHECK_LOSS_GRAD = _os.environ.get("SSDN_CHECK_LOSS_GRAD", "0") == "1"
+_MAX_ENGINES = 4        # cached (batch, size, mode) plans per Denoiser; the least recently used one is dropped beyond this
+
+
 class _ParallelShim(nn.Module):
     """Occupies the place of nn.DataParallel in the module tree so that checkpoints keep the
     `models.<id>.module.<param>` key layout (denoiser.py:102-110).  It parallelises nothing."""
@@ -39,19 +45,22 @@ class _LossBridge(torch.autograd.Function):
     gradient buffer through every parameter's `.grad`."""
 
     @staticmethod
-    def forward(ctx, anchor: Tensor, denoiser: "Denoiser", loss: Tensor):
-        ctx.denoiser = denoiser
+    def forward(ctx, anchor: Tensor, denoiser: "Denoiser", engine, loss: Tensor):
+        ctx.denoiser, ctx.engine = denoiser, engine        # the engine that PRODUCED this loss, not "the last one used"
         return loss.clone()
 
     @staticmethod
     def backward(ctx, grad_out: Tensor):
         d = ctx.denoiser
-        B = grad_out.shape[0]
-        if not torch.allclose(grad_out, torch.full_like(grad_out, 1.0 / B), rtol=1e-5, atol=0):
-            raise NotImplementedError("the fused loss head differentiates mean(LOSS) over the batch (train.py:201); "
-                                      "other reductions of LOSS are not supported")
-        d.backward()
-        return None, None, None
+        if grad_out.dim() != 2 or grad_out.shape[1] != 1:
+            raise NotImplementedError("LOSS is [B, 1]; the fused loss head differentiates mean(LOSS) over the batch (train.py:201)")
+        if _CHECK_LOSS_GRAD:      # debug aid (SSDN_CHECK_LOSS_GRAD=1): costs a host-device sync per step
+            B = grad_out.shape[0]
+            if not torch.allclose(grad_out, torch.full_like(grad_out, 1.0 / B), rtol=1e-5, atol=0):
+                raise NotImplementedError("the fused loss head differentiates mean(LOSS) over the batch (train.py:201); "
+                                          "other reductions of LOSS are not supported")
+        d._backward_engine(ctx.engine)
+        return None, None, None, None
 
 
 class Denoiser(nn.Module):
@@ -95,9 +104,11 @@ class Denoiser(nn.Module):
         self.l_params = nn.ParameterDict()
         if self._const:
             self.l_params[Denoiser.ESTIMATED_SIGMA] = nn.Parameter(self.flat[n_main + n_sig:n_main + n_sig + 1].view(1, 1, 1, 1))
-        self._engines: Dict[Tuple, list] = {}
+        self._engines: Dict[Tuple, list] = {}       # key -> [engine, parameter version its 16-bit weight shadows hold]
         self._version = 0
-        self._last_engine = None
+        self._last_engine = None                     # engine of the last run_pipeline (any mode)
+        self._last_train_engine = None               # engine of the last TRAINING-mode run_pipeline (backward / optimiser)
+        self._exchange = None                        # ssdn.hip.dp.GradExchange of train_step (data parallel)
         self._anchor = torch.zeros((), requires_grad=True)
 
     def _add(self, model_id: str, model: nn.Module):
@@ -130,7 +141,17 @@ class Denoiser(nn.Module):
         return d
 
     def mark_dirty(self):
+        """The fp32 parameters changed: the fp16/bf16 MFMA shadows are re-packed before the next run.  Calling this by hand
+        is only needed after writing the flat buffer through a raw pointer; every torch-visible in-place update (a
+        `torch.optim` step on the parameters, `load_state_dict`, `p.data.copy_()` ...) is detected through the version counter
+        of the flat buffer, which all parameter views share."""
         self._version += 1
+        for m in self._models.values():
+            if hasattr(m, "mark_dirty"):
+                m.mark_dirty()
+
+    def _param_version(self):
+        return (self._version, self.flat._version)
 
     # ---- engines ---------------------------------------------------------------------------------------------------
     def _engine(self, B: int, H: int, W: int, train: bool, ncoords: int = 64):
@@ -145,11 +166,19 @@ class Denoiser(nn.Module):
                                  cfg.get(ConfigValue.NOISE_STYLE) or "gauss", cfg[ConfigValue.NOISE_VALUE].value if self._pipeline == Pipeline.SSDN else "known",
                                  B, H, W, self.device, self.flat, self.flat_grad, self.adam_m, self.adam_v,
                                  self._n_main, self._n_sig, self._const, train=train, ncoords=ncoords)
-            self._engines[key] = [eng, -1]
-        slot = self._engines[key]
-        if slot[1] != self._version:
+            self._engines[key] = [eng, None]
+            while len(self._engines) > _MAX_ENGINES:         # LRU: a plan owns ~1 GB of buffers at BASELINE sizes
+                old = next(k for k in self._engines if k != key)
+                dead = self._engines.pop(old)[0]
+                if dead is self._last_engine:
+                    self._last_engine = None
+                if dead is self._last_train_engine:
+                    self._last_train_engine = None
+        slot = self._engines.pop(key)
+        self._engines[key] = slot                            # most recently used last
+        if slot[1] != self._param_version():
             slot[0].repack()
-            slot[1] = self._version
+            slot[1] = self._param_version()
         return slot[0]
 
     # ---- pipelines -------------------------------------------------------------------------------------------------
@@ -158,6 +187,11 @@ class Denoiser(nn.Module):
         return self.run_pipeline([data])[PipelineOutput.IMG_DENOISED]
 
     def run_pipeline(self, data: List, **kwargs) -> Dict:
+        """Reference surface (denoiser.py:128-138).  Outputs are fresh tensors, as in the reference: the caller may keep
+        them across calls.  (`train_step` uses the engine's buffers directly.)"""
+        return self._run(data, clone=True)
+
+    def _run(self, data: List, clone: bool) -> Dict:
         if self._pipeline not in (Pipeline.MSE, Pipeline.SSDN, Pipeline.MASK_MSE):
             raise NotImplementedError("Unsupported processing pipeline")
         inp = data[NoisyDataset.INPUT]
@@ -166,6 +200,10 @@ class Denoiser(nn.Module):
         meta = data[NoisyDataset.METADATA] if len(data) > NoisyDataset.METADATA else {}
         MD = NoisyDataset.Metadata
         coords = meta.get(MD.MASK_COORDS) if isinstance(meta, dict) else None
+        if coords is not None and coords.device.type == "cpu" and coords.numel():
+            c0 = coords[0]          # the reference indexes with batch element 0's coordinates and raises IndexError out of range
+            if int(c0[:, 0].min()) < -H or int(c0[:, 0].max()) >= H or int(c0[:, 1].min()) < -W or int(c0[:, 1].max()) >= W:
+                raise IndexError("mask coordinates out of range for a %dx%d image" % (H, W))
         train = self.training and torch.is_grad_enabled()
         eng = self._engine(B, H, W, train, ncoords=(coords.shape[1] if coords is not None else 64))
         eng.inp.copy_(inp.to(torch.float32), non_blocking=True)          # device boundary (denoiser.py:143,186)
@@ -178,36 +216,47 @@ class Denoiser(nn.Module):
             if have_loss:
                 eng.ref.copy_(ref.to(torch.float32), non_blocking=True)
                 if self._pipeline == Pipeline.MASK_MSE:
-                    eng.coords.copy_(coords[0].to(torch.int64), non_blocking=True)   # element 0's mask for everyone (n2v_loss.py:12)
+                    c0 = coords[0].to(torch.int64)
+                    c0 = torch.stack([c0[:, 0] % H, c0[:, 1] % W], 1)              # python-style negative indices wrap
+                    eng.coords.copy_(c0, non_blocking=True)   # element 0's mask for everyone (n2v_loss.py:12)
         if have_loss:
             eng.forward()
         else:
             eng.net_forward_only()
         self._last_engine = eng
+        if train:
+            self._last_train_engine = eng
+        own = (lambda t: t.clone()) if clone else (lambda t: t)
         out = {PipelineOutput.INPUTS: data}
         net_out = eng.main.tensor("out32")
         if self._pipeline == Pipeline.SSDN:
-            out[PipelineOutput.IMG_MU] = eng.mu
-            out[PipelineOutput.IMG_DENOISED] = eng.pme
+            out[PipelineOutput.IMG_MU] = own(eng.mu)
+            out[PipelineOutput.IMG_DENOISED] = own(eng.pme)
             gauss = eng.style == "gauss"
             nstd = eng.noise_std
             if gauss:
                 nstd = nstd[:1].view(1, 1, 1) if self._const else nstd.view(B, 1, 1)
-            out[PipelineOutput.NOISE_STD_DEV] = nstd
-            out[PipelineOutput.MODEL_STD_DEV] = eng.model_std
+            out[PipelineOutput.NOISE_STD_DEV] = own(nstd)
+            out[PipelineOutput.MODEL_STD_DEV] = own(eng.model_std)
         else:
-            out[PipelineOutput.IMG_DENOISED] = net_out
+            out[PipelineOutput.IMG_DENOISED] = own(net_out)
         if have_loss:
             loss = eng.loss
-            out[PipelineOutput.LOSS] = _LossBridge.apply(self._anchor, self, loss) if train else loss
+            # (_LossBridge.forward clones; the eval branch clones here)
+            out[PipelineOutput.LOSS] = _LossBridge.apply(self._anchor, self, eng, loss) if train else own(loss)
         return out
 
     def backward(self):
         """Run the planned backward pass of the last training-mode run_pipeline; gradients land in `flat_grad` and are
         visible as `.grad` of every parameter."""
-        eng = self._last_engine
+        eng = self._last_train_engine
         if eng is None or not eng.train:
             raise RuntimeError("backward() needs a preceding training-mode run_pipeline()")
+        self._backward_engine(eng)
+
+    def _backward_engine(self, eng):
+        if eng is None or not eng.train:
+            raise RuntimeError("this LOSS was not produced by a training-mode run_pipeline()")
         eng.backward()
         self._expose_grads()
 
@@ -222,22 +271,71 @@ class Denoiser(nn.Module):
             self.l_params[Denoiser.ESTIMATED_SIGMA].grad = self.flat_grad[o:o + 1].view(1, 1, 1, 1)
 
     def optimizer_step(self, lr: float, grad_scale: float = 1.0):
-        """Fused Adam (betas 0.9/0.99, eps 1e-8; train.py:100-107) over the flat buffer + re-pack of the fp16 MFMA shadows."""
-        eng = self._last_engine
+        """Fused Adam (betas 0.9/0.99, eps 1e-8; train.py:100-107) over the flat buffer + re-pack of the fp16 MFMA shadows.
+        Acts on the engine of the last TRAINING-mode run_pipeline (an eval / snapshot call in between does not matter)."""
+        eng = self._last_train_engine
+        if eng is None:
+            raise RuntimeError("optimizer_step() needs a preceding training-mode run_pipeline()")
         self.adam_steps += 1
         eng.adam(lr, self.adam_steps, grad_scale)
-        # shadows of THIS engine are fresh; other cached shapes re-pack lazily
-        self._version += 1
+        # the kernel wrote the flat buffer through a raw pointer: bump our own counter (torch's did not move); the shadows of
+        # THIS engine are fresh, other cached shapes and the nets' own forward engines re-pack lazily
+        self.mark_dirty()
         for slot in self._engines.values():
             if slot[0] is eng:
-                slot[1] = self._version
+                slot[1] = self._param_version()
 
-    def train_step(self, data: List, lr: float, allreduce=None) -> Dict:
-        """One whole optimisation step on this GPU: forward + loss + backward (+ gradient all-reduce) + Adam."""
-        out = self.run_pipeline(data)
-        self._last_engine.backward()
-        scale = 1.0
-        if allreduce is not None:
-            scale = allreduce(self.flat_grad)
+    def gradient_exchange(self, world: int):
+        """The bucketed, backward-overlapped all-reduce of this model's flat gradient (ssdn.hip.dp.GradExchange)."""
+        from ssdn.hip import dp
+        net = self._models[Denoiser.MODEL]
+        return dp.GradExchange(world, dp.bucket_ranges(net.layers, self._n_main, self.flat.numel()), self.device)
+
+    def train_step(self, data: List, lr: float, exchange=None) -> Dict:
+        """One whole optimisation step on this GPU: forward + loss + backward + Adam.  exchange: `gradient_exchange(world)`
+        for data parallelism -- the per-bucket all-reduces are issued behind events recorded inside the backward list, so
+        they overlap the rest of the backward pass; Adam waits for them and folds in 1 / world."""
+        from ssdn.hip import dp
+        out = self._run(data, clone=False)
+        eng = self._last_train_engine
+        scale = dp.exchange_step(lambda ex: eng.backward(exchange=ex), self.flat_grad, exchange)
         self.optimizer_step(lr, scale)
         return out
+
+    # ---- optimiser state in the reference's torch.optim.Adam layout (train.py:725,744: `.training` checkpoints) ----------
+    def _param_slices(self):
+        """(flat offset, numel, shape) of every parameter in `self.parameters()` order == the reference's order (the module
+        tree mirrors it, incl. output_conv registered before output_block and the de-duplicated `_models` aliases)."""
+        base = self.flat.data_ptr()
+        res = []
+        for p in self.parameters():
+            off = (p.data_ptr() - base) // 4
+            res.append((off, p.numel(), tuple(p.shape)))
+        return res
+
+    def optimizer_state_dict(self, lr: float = 3e-4) -> Dict:
+        """State of the fused Adam as `torch.optim.Adam(denoiser.parameters(), betas=[0.9, 0.99]).state_dict()` would have it."""
+        state = {}
+        sl = self._param_slices()
+        if self.adam_steps > 0:
+            for i, (off, n, shape) in enumerate(sl):
+                state[i] = {"step": torch.tensor(float(self.adam_steps)),
+                            "exp_avg": self.adam_m[off:off + n].view(shape).clone(),
+                            "exp_avg_sq": self.adam_v[off:off + n].view(shape).clone()}
+        group = {"lr": lr, "betas": (0.9, 0.99), "eps": 1e-8, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(sl)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_optimizer_state_dict(self, sd: Dict):
+        sl = self._param_slices()
+        self.adam_m.zero_()
+        self.adam_v.zero_()
+        steps = 0
+        for i, (off, n, shape) in enumerate(sl):
+            st = sd.get("state", {}).get(i)
+            if st is None:
+                continue
+            self.adam_m[off:off + n].copy_(st["exp_avg"].reshape(-1).to(self.adam_m))
+            self.adam_v[off:off + n].copy_(st["exp_avg_sq"].reshape(-1).to(self.adam_v))
+            steps = max(steps, int(float(st["step"])))
+        self.adam_steps = steps

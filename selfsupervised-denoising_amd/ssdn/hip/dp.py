@@ -1,19 +1,25 @@
 """Data parallelism for the ssdn hot path: one process per GPU, identical replicas, ONE exchange per step -- a
 sum-all-reduce of the flat fp32 gradient buffer over RCCL (torch.distributed backend "nccl" is RCCL on ROCm), averaged by
 folding 1/world into the fused Adam pass.  Replaces nn.DataParallel (reference: denoiser.py:102-110):
-no per-step parameter broadcast, no scatter/gather of activations, the loss head runs on every rank for its own shard.
+no per-step parameter broadcast, no scatter/gather of activations, the loss head runs on every rank for its own shard;
+the mean over the GLOBAL batch of the reference's `torch.mean(LOSS).backward()` (train.py:201) is reproduced exactly
+(every rank differentiates the mean over its shard, the sum over ranks is divided by the world size).
 
-The gradient is exchanged in up to three contiguous buckets of the flat buffer in the order the backward pass
-completes them (head+dec1 | dec2..dec5 | encoder [| sigma-net, learnable sigma]); every bucket's all-reduce is issued
-asynchronously right after the segment of the backward op list that finishes it, so RCCL traffic (5-10 MB, latency
-bound on xGMI) overlaps the rest of the backward pass.  With world_size 1 nothing is communicated.
+The gradient is exchanged in up to four contiguous buckets of the flat buffer, in the order the backward pass completes
+them (head+dec1 | dec2..dec5 | encoder | sigma-net + learnable sigma).  `GradExchange` overlaps the exchange with the
+backward pass WITHOUT splitting the backward op list: the list carries one SSDN_OP_EVENT_RECORD per bucket on the
+weight-gradient lane (right after the bucket's last slab reduction); the whole list is enqueued asynchronously, then each
+bucket's all-reduce is issued on a communication stream that waits for the bucket's event.  RCCL traffic (5-10 MB, latency
+bound on xGMI) therefore runs under the remaining backward kernels; the optimiser stream waits for the collectives only
+right before Adam.  With world_size 1 nothing is communicated.
 
-Everything here also runs on CPU tensors with the "gloo" backend (tests/test_dp_gloo.py).
+Everything here also runs on CPU tensors with the "gloo" backend (tests/test_dp_gloo.py), where "events" degenerate to
+program order.  NOTE: scaling across GPUs has not been measured on hardware by the builder (the driver owns 8-GPU runs).
 """
 from __future__ import annotations
 
 import os
-from typing import List, Optional, Tuple
+from typing import Callable, List, Optional, Sequence, Set, Tuple
 
 import torch
 import torch.distributed as dist
@@ -55,25 +61,95 @@ def bucket_ranges(layers, n_main: int, n_total: int) -> List[Tuple[int, int]]:
         ([(n_main, n_total)] if n_total > n_main else [])
 
 
-class GradAllReduce:
-    """Callable handed to Denoiser.train_step: sums `flat_grad` over ranks, returns the scale (1/world) Adam applies."""
+def bucket_layers(layers) -> List[Set[str]]:
+    """Layer names of the three main-net buckets of `bucket_ranges`, same order."""
+    off = {l.name: l.w_off for l in layers}
+    a, b = off["decode_block_1.0"], off["decode_block_5.0"]
+    return [{l.name for l in layers if l.w_off >= a}, {l.name for l in layers if b <= l.w_off < a},
+            {l.name for l in layers if l.w_off < b}]
 
-    def __init__(self, world: int):
-        self.world = world
-        self.pending = []
 
-    def bucket(self, flat_grad: torch.Tensor, lo: int, hi: int):
-        """Asynchronously all-reduce one finished bucket (called between backward segments)."""
-        if self.world > 1 and hi > lo:
-            self.pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+class GradExchange:
+    """Bucketed gradient all-reduce overlapped with the backward pass.
+
+        ex = GradExchange(world, bucket_ranges(...))
+        ... backward op list enqueued (it records ex.event_handles()[k] when bucket k is complete) ...
+        ex.launch(flat_grad)        # one asynchronous all-reduce per bucket, each behind its bucket's event
+        scale = ex.finish()         # the current stream waits for the collectives; returns 1 / world for Adam
+
+    On CUDA/HIP tensors the collectives are issued from a dedicated communication stream; on CPU tensors (gloo) the
+    events are absent and the buckets are reduced in order -- the control flow is the same."""
+
+    def __init__(self, world: int, ranges: Sequence[Tuple[int, int]], device: Optional[torch.device] = None,
+                 force_events: bool = False):
+        self.world, self.ranges = world, [(int(lo), int(hi)) for lo, hi in ranges]
+        self.pending: list = []
+        self.device = torch.device(device) if device is not None else None
+        self.cuda = self.device is not None and self.device.type == "cuda"
+        self.events: list = []
+        self.comm_stream = None
+        if self.cuda and (world > 1 or force_events):      # (force_events: single-GPU test of the event-carrying backward list)
+            self.comm_stream = torch.cuda.Stream(device=self.device)
+            for _ in self.ranges:
+                e = torch.cuda.Event(enable_timing=False, blocking=False)
+                e.record(torch.cuda.current_stream(self.device))        # creates the underlying hipEvent_t
+                self.events.append(e)
+
+    @property
+    def overlapped(self) -> bool:
+        return bool(self.events)
+
+    def event_handles(self) -> List[int]:
+        """raw hipEvent_t handles, one per bucket (for SSDN_OP_EVENT_RECORD)"""
+        return [int(e.cuda_event) for e in self.events]
+
+    def record_here(self, k: int):
+        """Bucket k is complete at the current position of the current stream (used for buckets whose producer is not
+        the main net's op list: the sigma-estimation network)."""
+        if self.events:
+            self.events[k].record(torch.cuda.current_stream(self.device))
+
+    def launch(self, flat_grad: torch.Tensor):
+        if self.world <= 1:
+            return
+        for k, (lo, hi) in enumerate(self.ranges):
+            if hi <= lo:
+                continue
+            if self.comm_stream is not None:
+                self.comm_stream.wait_event(self.events[k])
+                with torch.cuda.stream(self.comm_stream):
+                    self.pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+            else:
+                self.pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
 
     def finish(self) -> float:
         for w in self.pending:
-            w.wait()
+            w.wait()            # NCCL/RCCL: the CURRENT stream waits (no host block); gloo: host wait
         self.pending = []
         return 1.0 / self.world
 
+    # one blocking all-reduce of the whole buffer (kept for callers that do not overlap)
     def __call__(self, flat_grad: torch.Tensor) -> float:
         if self.world > 1:
             dist.all_reduce(flat_grad, op=dist.ReduceOp.SUM)
         return 1.0 / self.world
+
+
+def exchange_step(run_backward: Callable[[Optional[GradExchange]], None], flat_grad: torch.Tensor,
+                  exchange: Optional[GradExchange]) -> float:
+    """The gradient half of one data-parallel optimisation step -- the SAME code path for `Denoiser.train_step`,
+    `bench.py --gpus N` and the CPU/gloo test: enqueue the backward pass (which marks bucket completion on `exchange`),
+    launch the per-bucket all-reduces behind those marks, make the optimiser wait for them.  Returns the gradient scale
+    (1 / world) the fused Adam folds in."""
+    run_backward(exchange)
+    if exchange is None:
+        return 1.0
+    exchange.launch(flat_grad)
+    return exchange.finish()
+
+
+class GradAllReduce(GradExchange):
+    """Back-compatible name: one bucket = the whole flat buffer (no overlap)."""
+
+    def __init__(self, world: int):
+        super().__init__(world, [])

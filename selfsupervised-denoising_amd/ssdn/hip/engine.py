@@ -68,8 +68,38 @@ class DeviceNet:
             # zero-initialised once: padding channels / never-written slab corners must be finite
             self.t[name] = torch.zeros(spec.shape, dtype=self.DT[spec.kind], device=device)
         self.fwd = OpList([self._mat(op) for op in plan.fwd])
-        self.bwd = OpList(self._batch_side_ops([self._mat(op) for op in plan.bwd]), lanes=True)
+        self._bwd_recs = self._batch_side_ops([self._mat(op) for op in plan.bwd])
+        self._bwd_layers = [op.a.get("layer") if op.type == "wreduce" else None for op in plan.bwd] \
+            if len(self._bwd_recs) == len(plan.bwd) else None
+        self.bwd = OpList(self._bwd_recs, lanes=True)
         self.pack = OpList([self._mat(op) for op in plan.pack])
+
+    def bwd_with_events(self, buckets, events):
+        """Backward op list with one SSDN_OP_EVENT_RECORD per gradient bucket, placed on the weight-gradient lane right
+        after the LAST slab reduction of the bucket's layers.  buckets: list of sets of layer names in backward completion
+        order; events: raw hipEvent_t handles (ints), one per bucket.  Used by the overlapped gradient all-reduce
+        (ssdn.hip.dp): the RCCL stream waits for bucket k's event while the backward pass goes on."""
+        if self._bwd_layers is None:
+            raise L.SsdnHipError("bucket events need the un-batched backward list (SSDN_SIDE_BATCH=1)")
+        last = {}
+        for i, name in enumerate(self._bwd_layers):
+            if name is None:
+                continue
+            for k, b in enumerate(buckets):
+                if name in b:
+                    last[k] = i
+        recs = []
+        for i, r in enumerate(self._bwd_recs):
+            recs.append(r)
+            for k, idx in last.items():
+                if idx == i:
+                    recs.append(("event_record", L.EventArgs(events[k])))
+        ol = OpList.__new__(OpList)
+        OpList.__init__(ol, recs, lanes=True)
+        for j, r in enumerate(recs):                       # the record rides the weight-gradient lane
+            if r[0] == "event_record":
+                ol.arr[j].lane = 1
+        return ol
 
     @staticmethod
     def _batch_side_ops(recs, every: Optional[int] = None):
@@ -303,8 +333,21 @@ class DenoiserEngine:
         s = current_stream() if stream is None else stream
         self.main.fwd.run(s)
 
-    def backward(self, stream=None):
+    def backward(self, stream=None, exchange=None):
+        """Enqueue the backward pass.  exchange (ssdn.hip.dp.GradExchange, overlapped): the main net's list then carries one
+        event record per gradient bucket; the last bucket (sigma estimator / learnable sigma) is marked after its own list."""
         s = current_stream() if stream is None else stream
+        if exchange is not None and exchange.overlapped:
+            from .dp import bucket_layers
+            if getattr(self, "_bwd_ev_key", None) != id(exchange):
+                self._bwd_ev = self.main.bwd_with_events(bucket_layers(self.main.plan.layers), exchange.event_handles()[:3])
+                self._bwd_ev_key = id(exchange)
+            self._bwd_ev.run(s)
+            if self.sigma is not None:
+                self.sigma.bwd.run(s)
+            if len(exchange.ranges) > 3:
+                exchange.record_here(3)
+            return
         self.main.bwd.run(s)
         if self.sigma is not None:
             self.sigma.bwd.run(s)

@@ -15,7 +15,7 @@ MAX_TAPS = 9
 # op type codes (enum ssdn_op_type)
 OP = dict(pack_input=1, conv=2, pool_fwd=3, pool_bwd=4, upsum_bwd=5, unrot_fwd=6, unrot_bwd=7, wgrad=8, wreduce=9,
           wpack=10, grad_pack=11, head_ssdn=12, head_final=13, spatial_mean=14, mse=15, mask_mse=16, adam=17,
-          sqerr=18, zero=19)
+          sqerr=18, zero=19, event_record=20)
 
 i32, f32, vp = C.c_int32, C.c_float, C.c_void_p
 
@@ -108,10 +108,14 @@ class ZeroArgs(C.Structure):
     _fields_ = [("p", vp), ("bytes", C.c_int64)]
 
 
+class EventArgs(C.Structure):
+    _fields_ = [("event", vp)]
+
+
 ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, pool_bwd=PoolArgs, upsum_bwd=UpsumArgs,
                  unrot_fwd=UnrotArgs, unrot_bwd=UnrotArgs, wgrad=WgradArgs, wreduce=WreduceArgs, wpack=WpackArgs,
                  grad_pack=GradPackArgs, head_ssdn=HeadArgs, head_final=HeadFinalArgs, spatial_mean=SpatialMeanArgs,
-                 mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs)
+                 mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs, event_record=EventArgs)
 
 # every symbol include/ssdn_hip.h declares
 ABI_VERSION = 4      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors

@@ -143,8 +143,12 @@ class NoiseNetwork(nn.Module):
         if key not in self._engines:
             cus = L.load().ssdn_device_cus()
             plan = NetPlan("n/", self.in_channels, self.out_channels, self._blindspot, B, H, W, cus=cus, train=False)
-            self._engines[key] = [DeviceNet(plan, self._flat.device, self._flat, None), -1]
-        return self._engines[key]
+            self._engines[key] = [DeviceNet(plan, self._flat.device, self._flat, None), None]
+            while len(self._engines) > 4:                  # LRU cap: a plan owns all its activation buffers
+                self._engines.pop(next(k for k in self._engines if k != key))
+        slot = self._engines.pop(key)
+        self._engines[key] = slot
+        return slot
 
     def forward(self, x: Tensor) -> Tensor:
         """x: float32 [B,C,H,W] (H, W multiples of 32; square when blindspot) -> float32 [B,out_channels,H,W] on the GPU."""
@@ -155,9 +159,10 @@ class NoiseNetwork(nn.Module):
         slot = self._engine(B, H, W)
         eng = slot[0]
         s = current_stream()
-        if slot[1] != self._version:
+        ver = (self._version, self._flat._version)     # torch-visible in-place updates move the buffer's own counter
+        if slot[1] != ver:
             eng.pack.run(s)
-            slot[1] = self._version
+            slot[1] = ver
         eng.tensor("in32").copy_(x.to(dtype=torch.float32), non_blocking=True)
         eng.fwd.run(s)
         return eng.tensor("out32").clone()

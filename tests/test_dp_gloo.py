@@ -1,7 +1,8 @@
-"""N > 1 path on CPU: two gloo processes, each computing the gradient of ITS shard (compute stand-in = the oracle, this is
-a test), all-reduced with ssdn.hip.dp.GradAllReduce and averaged the way the fused Adam does (gscale = 1/world).  The result
-must equal the single-process gradient of the whole batch -- i.e. the W-GPU run optimises mean(LOSS) over the global batch
-exactly like the reference's DataParallel run (train.py:201)."""
+"""N > 1 path on CPU: two gloo processes drive the SAME step-driver code `Denoiser.train_step` / `bench.py --gpus N` use
+(`ssdn.hip.dp.exchange_step` + `GradExchange` with the real bucket ranges of a network), with a stub engine whose backward is
+the oracle (this is a test) writing the shard's gradient into the flat layout.  The bucketed exchange, scaled by the 1/world
+the fused Adam folds in, must equal the single-process gradient of the whole batch -- i.e. the W-GPU run optimises
+mean(LOSS) over the global batch exactly like the reference's DataParallel run (train.py:201)."""
 import os
 import socket
 
@@ -12,6 +13,7 @@ import torch.multiprocessing as mp
 
 import restate as R
 from ssdn.hip import dp
+from ssdn.hip.graph import net_layers, net_param_count
 
 
 def _free_port():
@@ -22,8 +24,38 @@ def _free_port():
     return p
 
 
+LAYERS = net_layers(1, 1, False)
+NPAR = net_param_count(LAYERS)
+
+
 def _flat_grad(tr):
-    return torch.cat([t.grad.reshape(-1) for t in tr.leaves])
+    """oracle gradients -> the Denoiser's flat parameter layout"""
+    f = torch.zeros(NPAR + 1)                      # + one slot standing for the learnable-sigma scalar (4th bucket)
+    for l in LAYERS:
+        f[l.w_off:l.w_off + l.M * l.cin * l.k * l.k] = tr.p[l.name + ".weight"].grad.reshape(-1)
+        f[l.b_off:l.b_off + l.M] = tr.p[l.name + ".bias"].grad
+    f[NPAR] = float(sum(float(t.grad.sum()) for t in tr.leaves[:2]))
+    return f
+
+
+class StubEngine:
+    """stands where DenoiserEngine stands in Denoiser.train_step: backward(exchange=...) fills the flat gradient"""
+
+    def __init__(self, rank, world):
+        B, P = 4, 32
+        lo, hi = dp.shard_rows(B, rank, world)
+        self.noisy = R.hash_tensor((B, 1, P, P), 5, 0, 1)[lo:hi]
+        self.clean = R.hash_tensor((B, 1, P, P), 6, 0, 1)[lo:hi]
+        self.tr = R.CpuTrainer("n2c", 1, seed=3)
+        self.flat_grad = torch.zeros(NPAR + 1)
+        self.seen_exchange = None
+
+    def backward(self, exchange=None):
+        for t in self.tr.leaves:
+            t.grad = None
+        self.tr.forward(self.noisy, self.clean)["loss"].mean().backward()
+        self.flat_grad.copy_(_flat_grad(self.tr))
+        self.seen_exchange = exchange
 
 
 def _worker(rank, world, port, out):
@@ -31,26 +63,19 @@ def _worker(rank, world, port, out):
     torch.set_num_threads(2)
     r, w, _ = dp.init_from_env("gloo")
     assert (r, w) == (rank, world)
-    B, P = 4, 32
-    noisy = R.hash_tensor((B, 1, P, P), 5, 0, 1)
-    clean = R.hash_tensor((B, 1, P, P), 6, 0, 1)
-    lo, hi = dp.shard_rows(B, rank, world)
-    tr = R.CpuTrainer("n2c", 1, seed=3)
-    res = tr.forward(noisy[lo:hi], clean[lo:hi])
-    res["loss"].mean().backward()
-    flat = _flat_grad(tr)
-    ar = dp.GradAllReduce(world)
-    # bucketed, asynchronous form (what overlaps with the backward pass on the GPU)
-    n = flat.numel()
-    for lo_, hi_ in ((n // 2, n), (0, n // 2)):
-        ar.bucket(flat, lo_, hi_)
-    scale = ar.finish()
-    flat2 = _flat_grad(tr)
-    scale2 = ar(flat2)                       # monolithic form
+    eng = StubEngine(rank, world)
+    ex = dp.GradExchange(world, dp.bucket_ranges(LAYERS, NPAR, NPAR + 1), torch.device("cpu"))
+    assert not ex.overlapped and len(ex.ranges) == 4
+    # the step driver of Denoiser.train_step / bench.py
+    scale = dp.exchange_step(lambda e: eng.backward(exchange=e), eng.flat_grad, ex)
+    assert eng.seen_exchange is ex and ex.pending == []
+    bucketed = (eng.flat_grad * scale).clone()
+    eng.backward()
+    scale2 = ex(eng.flat_grad)               # monolithic form
     if rank == 0:
         # numpy, not torch tensors: a tensor in a Queue is shared through a file descriptor the consumer must fetch from
         # THIS process, which may already have exited when a loaded host gets round to unpickling (EOFError)
-        out.put(((flat * scale).numpy(), (flat2 * scale2).numpy()))
+        out.put((bucketed.numpy(), (eng.flat_grad * scale2).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,11 +107,9 @@ def _run_world(world):
 
 def test_two_rank_gradient_equals_single_process():
     got_bucketed, got_mono = (torch.from_numpy(a) for a in _run_world(2))
-    B, P = 4, 32
-    tr = R.CpuTrainer("n2c", 1, seed=3)
-    res = tr.forward(R.hash_tensor((B, 1, P, P), 5, 0, 1), R.hash_tensor((B, 1, P, P), 6, 0, 1))
-    res["loss"].mean().backward()
-    want = _flat_grad(tr)
+    eng = StubEngine(0, 1)                       # world 1: the whole batch
+    assert dp.exchange_step(lambda e: eng.backward(exchange=e), eng.flat_grad, None) == 1.0
+    want = eng.flat_grad
     # fp32 CPU convolutions sum in a thread-partition dependent order (2 threads per rank vs the parent's pool; the split can
     # change with host load): tolerance relative to the gradient's scale, not to each element
     tol = 2e-5 * float(want.abs().max())

@@ -151,6 +151,126 @@ def test_reference_training_idiom_backward_bridge():
     assert float((w.detach() - before).abs().max()) > 0
 
 
+def test_external_optimizer_step_refreshes_the_weight_shadows():
+    """The reference idiom end to end, twice: after `torch.optim.Adam.step()` on the parameter views the NEXT run_pipeline must
+    see the new weights (the fp16/bf16 MFMA shadows are re-packed when the flat buffer's version counter moves) -- and the
+    same for NoiseNetwork.forward of the owned model."""
+    from ssdn.denoiser import Denoiser
+    from ssdn.datasets import NoisyDataset
+    from ssdn.params import PipelineOutput
+    d = make_denoiser("ssdn", "gauss25", "known", 3)
+    d.train()
+    clean, noisy, ref, coords, npar = train_inputs("ssdn", "gauss25", 3)
+    meta = {NoisyDataset.Metadata.INPUT_NOISE_VALUES: npar, NoisyDataset.Metadata.CLEAN: clean}
+    opt = torch.optim.Adam(d.parameters(), lr=2e-5, betas=[0.9, 0.99])     # (these fixtures sit on a very steep loss surface)
+    net = d.get_model(Denoiser.MODEL, False)
+    losses, outs = [], []
+    for _ in range(3):
+        opt.zero_grad()
+        out = d.run_pipeline([noisy, ref, meta])
+        outs.append(net(noisy.to("cuda:0")).cpu())
+        torch.mean(out[PipelineOutput.LOSS]).backward()
+        losses.append(float(out[PipelineOutput.LOSS].mean()))
+        opt.step()
+    assert losses[0] != losses[1] and losses[1] != losses[2], losses
+    assert losses[2] < losses[0], losses                          # and it actually descends
+    assert not torch.equal(outs[0], outs[1])                      # NoiseNetwork.forward sees the update too
+    # the fused path afterwards: train_step changes the next loss as well
+    d.train_step([noisy, ref, meta], lr=2e-5)
+    before = float(d.run_pipeline([noisy, ref, meta])[PipelineOutput.LOSS].mean())
+    d.train_step([noisy, ref, meta], lr=2e-5)
+    assert float(d.run_pipeline([noisy, ref, meta])[PipelineOutput.LOSS].mean()) != before
+
+
+def test_loss_backward_uses_its_own_engine_and_outputs_are_fresh_tensors():
+    """An eval / differently shaped run_pipeline between a training forward and `.backward()` must not disturb it (the LOSS
+    carries the engine that produced it), and results of one call survive the next call (fresh tensors, like the reference)."""
+    from ssdn.datasets import NoisyDataset
+    from ssdn.params import PipelineOutput
+    d = make_denoiser("ssdn", "gauss25", "known", 3)
+    clean, noisy, ref, coords, npar = train_inputs("ssdn", "gauss25", 3)
+    meta = {NoisyDataset.Metadata.INPUT_NOISE_VALUES: npar, NoisyDataset.Metadata.CLEAN: clean}
+    d.train()
+    out = d.run_pipeline([noisy, ref, meta])
+    d.backward()
+    torch.cuda.synchronize()
+    g_ref = d.flat_grad.clone()
+    d.flat_grad.zero_()
+    out = d.run_pipeline([noisy, ref, meta])
+    kept = out[PipelineOutput.IMG_DENOISED]
+    kept_copy = kept.clone()
+    d.eval()
+    with torch.no_grad():
+        other = d.run_pipeline([noisy[:1].flip(2), None, {NoisyDataset.Metadata.INPUT_NOISE_VALUES: npar[:1]}])   # another engine
+        same_shape = d.run_pipeline([noisy * 0.5, None, meta])                                                      # and an eval one of the same shape
+    d.train()
+    torch.mean(out[PipelineOutput.LOSS]).backward()
+    torch.cuda.synchronize()
+    assert torch.equal(d.flat_grad, g_ref)
+    assert torch.equal(kept, kept_copy) and not torch.equal(kept, same_shape[PipelineOutput.IMG_DENOISED])
+    d.optimizer_step(1e-4)            # acts on the training engine although eval engines ran last
+
+
+def test_optimizer_state_dict_round_trip_in_reference_layout():
+    """`.training` checkpoints carry torch.optim.Adam.state_dict() (train.py:725): export after fused steps, load into a real
+    torch.optim.Adam over denoiser.parameters(), and back into a fresh Denoiser."""
+    from ssdn.datasets import NoisyDataset
+    d = make_denoiser("ssdn", "gauss25", "const", 3)
+    d.train()
+    clean, noisy, ref, coords, npar = train_inputs("ssdn", "gauss25", 3)
+    meta = {NoisyDataset.Metadata.INPUT_NOISE_VALUES: npar, NoisyDataset.Metadata.CLEAN: clean}
+    for _ in range(2):
+        d.train_step([noisy, ref, meta], lr=1e-4)
+    sd = d.optimizer_state_dict(lr=1e-4)
+    params = list(d.parameters())
+    assert len(sd["state"]) == len(params) == len(sd["param_groups"][0]["params"])
+    opt = torch.optim.Adam(d.parameters(), lr=1e-4, betas=[0.9, 0.99])
+    opt.load_state_dict(sd)                                                    # the layout torch expects
+    for i, p in enumerate(params):
+        assert opt.state[p]["exp_avg"].shape == p.shape and float(opt.state[p]["step"]) == 2.0
+    d2 = make_denoiser("ssdn", "gauss25", "const", 3)
+    d2.load_state_dict(d.state_dict())
+    d2.load_optimizer_state_dict(opt.state_dict())
+    assert d2.adam_steps == 2 and torch.equal(d2.adam_m, d.adam_m) and torch.equal(d2.adam_v, d.adam_v)
+    d.train_step([noisy, ref, meta], lr=1e-4)
+    d2.train()
+    d2.train_step([noisy, ref, meta], lr=1e-4)
+    torch.cuda.synchronize()
+    assert torch.equal(d.flat, d2.flat)                                       # resumed run == uninterrupted run, bit for bit
+
+
+def test_backward_with_bucket_events_is_bit_identical():
+    """Data parallel step driver on one GPU: the backward list that carries the bucket event records (what the RCCL stream
+    waits on) produces bit-identical gradients to the plain list, and every bucket's event completes."""
+    from ssdn.datasets import NoisyDataset
+    from ssdn.hip import dp
+    from ssdn.denoiser import Denoiser
+    d = make_denoiser("ssdn", "gauss25", "var", 3)
+    d.train()
+    clean, noisy, ref, coords, npar = train_inputs("ssdn", "gauss25", 3)
+    meta = {NoisyDataset.Metadata.INPUT_NOISE_VALUES: npar, NoisyDataset.Metadata.CLEAN: clean}
+    d._run([noisy, ref, meta], clone=False)
+    eng = d._last_train_engine
+    eng.backward()
+    torch.cuda.synchronize()
+    g_plain = d.flat_grad.clone()
+    d.flat_grad.fill_(float("nan"))
+    net = d.get_model(Denoiser.MODEL, False)
+    ex = dp.GradExchange(1, dp.bucket_ranges(net.layers, d._n_main, d.flat.numel()), d.device, force_events=True)
+    assert ex.overlapped and len(ex.ranges) == 4
+    d._run([noisy, ref, meta], clone=False)
+    scale = dp.exchange_step(lambda e: eng.backward(exchange=e), d.flat_grad, ex)
+    torch.cuda.synchronize()
+    assert scale == 1.0 and all(e.query() for e in ex.events)
+    n = d._n_main + d._n_sig                      # (the buffer is padded to a multiple of 4; padding is never written)
+    assert torch.equal(d.flat_grad[:n], g_plain[:n])
+    # ranges cover the buffer exactly once
+    cov = torch.zeros(d.flat.numel())
+    for lo, hi in ex.ranges:
+        cov[lo:hi] += 1
+    assert bool((cov[:d._n_main + d._n_sig] == 1).all())
+
+
 def test_eval_forward_any_square_size():
     """Inference at a non-training size (eval pads Kodak to 768x768, BSD300 to 512x512; here 96x96 to stay small):
     Denoiser.forward == IMG_DENOISED of the pipeline, vs the oracle."""

@@ -141,7 +141,7 @@ def train_inputs(alg, style, ch, P=32, Bn=2):
     npar = 25 / 255.0 if style.startswith("gauss") else 30.0
     noisy = torch.clamp(clean + (R.hash_tensor((Bn, ch, P, P), 62, -1, 1)) * 0.17, 0, 1)
     ref = clean if alg != "n2v" else torch.clamp(clean + R.hash_tensor((Bn, ch, P, P), 63, -1, 1) * 0.17, 0, 1)
-    coords = R.hash_tensor((Bn, 16, 2), 64, 0, P).long()
+    coords = R.hash_tensor((Bn, 64, 2), 64, 0, P).long()
     return clean, noisy, ref, coords, torch.full((Bn, 1, 1, 1), npar)
 
 
