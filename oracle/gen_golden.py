@@ -33,6 +33,10 @@ def save(name, **arrs):
     print("wrote", name, {k: tuple(np.asarray(v.detach() if isinstance(v, torch.Tensor) else v).shape) for k, v in arrs.items()})
 
 
+def RefNoisy_null():
+    return torch.zeros(0)
+
+
 def main():
     ref = ref_shim.import_reference()
     with ref_shim.reference_modules(ref):
@@ -238,6 +242,101 @@ def main():
             ck[tag] = {"keys": [k for k in sd.keys()], "shapes": {k: list(v.shape) for k, v in sd.items() if hasattr(v, "shape")},
                        "globals": globs, "config_name": d.config_name(),
                        "cfg": {k.name: (v.name if hasattr(v, "name") else v) for k, v in sd["cfg"].items()}}
+        # ---- G10b `.training` contract: a state_dict written by the reference's OWN DenoiserTrainer -------------------
+        from ssdn.train import DenoiserTrainer
+        from ssdn.datasets import FixedLengthSampler, NoisyDataset as RefNoisy
+        from ssdn.params import StateValue, HistoryValue
+        tcfg = make_cfg("ssdn", "gauss25", "known", 3)
+        tr = DenoiserTrainer(tcfg, runs_dir="/tmp/ssdn_ref_runs")
+        tr.new_target()
+        tr.train_sampler = FixedLengthSampler(list(range(7)), num_samples=20, shuffled=True)
+        _ = iter(tr.train_sampler)
+        # two real optimiser steps so that the Adam state exists
+        Bn, P = 2, 32
+        noisy = torch.clamp(R.hash_tensor((Bn, 3, P, P), 61, 0, 1) + R.hash_tensor((Bn, 3, P, P), 62, -1, 1) * 0.17, 0, 1)
+        meta = {MD.INPUT_NOISE_VALUES: torch.full((Bn, 1, 1, 1), 25 / 255.0), MD.CLEAN: noisy, MD.IMAGE_SHAPE: None}
+        for _i in range(2):
+            opt = tr.optimizer
+            opt.zero_grad()
+            o = tr.denoiser.run_pipeline([noisy, RefNoisy_null(), meta]) if False else tr.denoiser.run_pipeline([noisy, noisy, meta])
+            torch.mean(o[PipelineOutput.LOSS]).backward()
+            opt.step()
+            tr.state[StateValue.HISTORY][HistoryValue.TRAIN]["loss"] += o[PipelineOutput.LOSS].detach()
+            tr.state[StateValue.HISTORY][HistoryValue.TRAIN]["n"] += Bn
+            tr.state[StateValue.ITERATION] += Bn
+        tr.state[StateValue.HISTORY][HistoryValue.TIMINGS]["total"].update()
+        tsd = tr.state_dict()
+        buf = io.BytesIO()
+        torch.save(tsd, buf)
+        import zipfile
+        zf = zipfile.ZipFile(io.BytesIO(buf.getvalue()))
+        pk = [n for n in zf.namelist() if n.endswith("data.pkl")][0]
+        tglobs = sorted({"%s.%s" % (a.split(" ")[0], a.split(" ")[1]) for op, a, _ in pickletools.genops(zf.read(pk))
+                         if op.name == "GLOBAL"})
+        osd = tsd["optimizer"]
+        ck["training_file"] = {
+            "keys": sorted(tsd.keys()), "globals": tglobs,
+            "state_keys": sorted(k.name for k in tsd["state"].keys()),
+            "history_keys": sorted(k.name for k in tsd["state"][StateValue.HISTORY].keys()),
+            "train_order_iter_keys": sorted(tsd["train_order_iter"].keys()),
+            "train_order_index": int(tsd["train_order_iter"]["index"]),
+            "optimizer_keys": sorted(osd.keys()),
+            "optimizer_group_keys": sorted(osd["param_groups"][0].keys()),
+            "optimizer_state_entry_keys": sorted(osd["state"][0].keys()),
+            "optimizer_n_params": len(osd["param_groups"][0]["params"]),
+            "optimizer_param_shapes": [list(osd["state"][i]["exp_avg"].shape) for i in range(len(osd["state"]))],
+            "optimizer_betas": list(osd["param_groups"][0]["betas"]),
+            "run_dir": tr.run_dir, "config_name": tr.config_name(),
+        }
+        # a reference-written `.training` file as a data fixture.  To keep it small every large tensor is zeroed first (zeros
+        # deflate to nothing); the 9 output biases and their Adam moments keep recognisable values for a round-trip check.
+        import gzip
+        with torch.no_grad():
+            for k, v in tsd["denoiser"].items():
+                if torch.is_tensor(v) and v.numel() > 16:
+                    v.zero_()
+            tsd["denoiser"]["models.denoiser_model.module.output_conv.bias"].copy_(torch.arange(9.0) * 0.25 - 1)
+            for i, st in osd["state"].items():
+                if st["exp_avg"].numel() > 16:
+                    st["exp_avg"].zero_()
+                    st["exp_avg_sq"].zero_()
+        buf2 = io.BytesIO()
+        torch.save(tsd, buf2)
+        with gzip.open(os.path.join(OUT, "g_training_file.training.gz"), "wb", compresslevel=9) as f:
+            f.write(buf2.getvalue())
+
+        # ---- G12 data layer: padding shapes, style parsing, n2v coordinate statistics --------------------------------
+        import ssdn.utils.noise as ref_noise
+        import ssdn.utils.n2v_ups as ref_ups
+        dl = {}
+        class _Imgs(torch.utils.data.Dataset):
+            def __init__(self, shapes): self.shapes = shapes
+            def __len__(self): return len(self.shapes)
+            def __getitem__(self, i): return (R.hash_tensor(self.shapes[i], 900 + i, 0, 1), i)
+        for tag, shapes, kw in (("kodak_like", [(3, 48, 72), (3, 72, 48)], dict(pad_uniform=True, pad_multiple=32, square=True)),
+                                ("bsd_like", [(3, 33, 50), (3, 50, 33)], dict(pad_uniform=True, pad_multiple=32, square=False)),
+                                ("train_like", [(3, 64, 64)], dict(pad_uniform=False, pad_multiple=32, square=True))):
+            nd = RefNoisy(_Imgs(shapes), "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, training_mode=False, **kw)
+            inp, ref_, md_ = nd[0]
+            dl[tag] = {"out_shape": list(inp.shape), "image_shape": [int(v) for v in md_[MD.IMAGE_SHAPE]],
+                       "clean_padded_sum": float(md_[MD.CLEAN].double().sum()),
+                       "noise_values_shape": list(md_[MD.INPUT_NOISE_VALUES].shape), "ref_numel": int(ref_.numel())}
+        torch.manual_seed(7)
+        styles = {}
+        for st in ("gauss25", "gauss5_50", "gauss0.1", "gauss25_nc", "poisson30", "poisson5_50"):
+            x = torch.full((4, 3, 64, 64), 0.5)
+            y, coeff = ref_noise.add_style(x, st)
+            styles[st] = {"coeff": (coeff.reshape(-1).tolist() if torch.is_tensor(coeff) else float(coeff)),
+                          "coeff_shape": (list(coeff.shape) if torch.is_tensor(coeff) else []),
+                          "mean": float(y.mean()), "std": float((y - 0.5).std()), "min": float(y.min()), "max": float(y.max())}
+        dl["styles"] = styles
+        torch.manual_seed(11)
+        img = R.hash_tensor((3, 64, 64), 77, 0, 1)
+        out_img, coords = ref_ups.manipulate(img, 5)
+        dl["n2v"] = {"ncoords": int(coords.shape[0]), "coords_shape": list(coords.shape),
+                     "changed_pixels": int(((out_img != img).any(0)).sum()),
+                     "coord_max": int(coords.max()), "coord_min": int(coords.min())}
+        ck["data_layer"] = dl
         with open(os.path.join(OUT, "g_ckpt_contract.json"), "w") as f:
             json.dump(ck, f, indent=1, sort_keys=True)
         print("wrote g_ckpt_contract.json")

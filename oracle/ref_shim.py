@@ -86,8 +86,10 @@ def import_reference():
     _stub("torch.utils.tensorboard.writer", SummaryWriter=_Any)
     _stub("nptyping", Array=_Any)
 
-    # make sure OUR `ssdn` (same import name) is not the one that resolves
-    for k in [k for k in sys.modules if k == "ssdn" or k.startswith("ssdn.")]:
+    # make sure OUR `ssdn` (same import name) is not the one that resolves -- and put it back afterwards, so that objects
+    # already imported from it keep their identity (pickling checks `sys.modules[cls.__module__].<name> is cls`)
+    ours = {k: v for k, v in sys.modules.items() if k == "ssdn" or k.startswith("ssdn.")}
+    for k in ours:
         del sys.modules[k]
     sys.path.insert(0, REF_ROOT)
     try:
@@ -99,6 +101,7 @@ def import_reference():
     mods = {k: v for k, v in sys.modules.items() if k == "ssdn" or k.startswith("ssdn.")}
     for k in mods:
         del sys.modules[k]
+    sys.modules.update(ours)
     ref._all_modules = mods
     return ref
 

