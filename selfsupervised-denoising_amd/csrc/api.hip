@@ -200,7 +200,16 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_UNROT_FWD: rc = launch_unrot_fwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_UNROT_BWD: rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_WGRAD: rc = launch_wgrad((const ssdn_wgrad_args*)p, s); break;
-            case SSDN_OP_WREDUCE: rc = launch_wreduce((const ssdn_wreduce_args*)p, s); break;
+            case SSDN_OP_WREDUCE: {   // a run of consecutive reductions on the same lane is two launches in total
+                const ssdn_wreduce_args* items[WREDUCE_MULTI_MAX];
+                int m = 0;
+                while (m < WREDUCE_MULTI_MAX && i + m < n && ops[i + m].type == SSDN_OP_WREDUCE && ops[i + m].args &&
+                       (one_lane ? 0 : ops[i + m].lane) == lane)
+                    items[m] = (const ssdn_wreduce_args*)ops[i + m].args, ++m;
+                rc = m > 1 ? launch_wreduce_multi(items, m, s) : launch_wreduce((const ssdn_wreduce_args*)p, s);
+                i += m - 1;
+                break;
+            }
             case SSDN_OP_WPACK: {   // a run of consecutive re-packs on the same lane is one launch
                 const ssdn_wpack_args* items[WPACK_MULTI_MAX];
                 int m = 0;

@@ -91,6 +91,8 @@ int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s);
 int launch_wpack(const ssdn_wpack_args* a, hipStream_t s);
 #define WPACK_MULTI_MAX 24
 int launch_wpack_multi(const ssdn_wpack_args* const* items, int n, hipStream_t s);
+#define WREDUCE_MULTI_MAX 32
+int launch_wreduce_multi(const ssdn_wreduce_args* const* items, int n, hipStream_t s);
 int launch_grad_pack(const ssdn_grad_pack_args* a, hipStream_t s);
 int launch_head(const ssdn_head_args* a, hipStream_t s);
 int launch_head_final(const ssdn_head_final_args* a, hipStream_t s);

@@ -68,9 +68,7 @@ class DeviceNet:
             # zero-initialised once: padding channels / never-written slab corners must be finite
             self.t[name] = torch.zeros(spec.shape, dtype=self.DT[spec.kind], device=device)
         self.fwd = OpList([self._mat(op) for op in plan.fwd])
-        self._bwd_recs = self._batch_side_ops([self._mat(op) for op in plan.bwd])
-        self._bwd_layers = [op.a.get("layer") if op.type == "wreduce" else None for op in plan.bwd] \
-            if len(self._bwd_recs) == len(plan.bwd) else None
+        self._bwd_recs, self._bwd_layers = self._group_reductions(plan, [self._mat(op) for op in plan.bwd])
         self.bwd = OpList(self._bwd_recs, lanes=True)
         self.pack = OpList([self._mat(op) for op in plan.pack])
 
@@ -79,8 +77,6 @@ class DeviceNet:
         after the LAST slab reduction of the bucket's layers.  buckets: list of sets of layer names in backward completion
         order; events: raw hipEvent_t handles (ints), one per bucket.  Used by the overlapped gradient all-reduce
         (ssdn.hip.dp): the RCCL stream waits for bucket k's event while the backward pass goes on."""
-        if self._bwd_layers is None:
-            raise L.SsdnHipError("bucket events need the un-batched backward list (SSDN_SIDE_BATCH=1)")
         last = {}
         for i, name in enumerate(self._bwd_layers):
             if name is None:
@@ -100,6 +96,37 @@ class DeviceNet:
             if r[0] == "event_record":
                 ol.arr[j].lane = 1
         return ol
+
+    @staticmethod
+    def _group_reductions(plan, recs):
+        """Move every slab reduction to the end of its gradient bucket (ssdn.hip.dp.bucket_layers: head+dec1 | dec2..dec5 |
+        encoder): the executor merges a run of consecutive SSDN_OP_WREDUCE ops into two launches, instead of two launches per
+        layer (51 latency-bound launches, 0.52 ms per step in situ).  Legal: every weight-gradient launch owns its slab and
+        the flat gradient is only read after the backward list.  Returns (records, layer name of each record if it is a
+        reduction else None)."""
+        from .dp import bucket_layers
+        if os.environ.get("SSDN_NO_WREDUCE_GROUPS") or not plan.bwd:
+            return recs, [op.a.get("layer") if op.type == "wreduce" else None for op in plan.bwd]
+        buckets = bucket_layers(plan.layers)
+        bucket_of = {name: k for k, b in enumerate(buckets) for name in b}
+        last = {}
+        for i, op in enumerate(plan.bwd):
+            if op.type in ("wgrad", "wreduce"):
+                last[bucket_of[op.a["layer"]]] = i
+        out, names, pending = [], [], {k: [] for k in range(len(buckets))}
+        for i, (op, rec) in enumerate(zip(plan.bwd, recs)):
+            if op.type == "wreduce":
+                pending[bucket_of[op.a["layer"]]].append((rec, op.a["layer"]))
+            else:
+                out.append(rec)
+                names.append(None)
+            for k, idx in last.items():
+                if idx == i:
+                    for rec_k, name_k in pending[k]:
+                        out.append(rec_k)
+                        names.append(name_k)
+                    pending[k] = []
+        return out, names
 
     @staticmethod
     def _batch_side_ops(recs, every: Optional[int] = None):

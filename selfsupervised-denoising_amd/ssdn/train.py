@@ -401,7 +401,12 @@ class DenoiserTrainer:
             torch.manual_seed(1234 + self.state.get(StateValue.ITERATION, 0))      # the same global order on every rank
         sampler = FixedLengthSampler(dataset, num_samples=cfg[ConfigValue.TRAIN_ITERATIONS], shuffled=True)
         if self._train_iter is not None:
-            sampler.for_next_iter(self._train_iter)
+            order = self._train_iter
+            missing = cfg[ConfigValue.TRAIN_ITERATIONS] - len(order.order)
+            if missing > 0:      # resumed with MORE iterations than the stored order holds (the reference would stop short with
+                extra = FixedLengthSampler(dataset, num_samples=missing, shuffled=True)      # StopIteration): extend it
+                order = SamplingOrder(list(order.order) + list(extra.sampler()), order.index)
+            sampler.for_next_iter(order)
             self._train_iter = None
         kw = dict(num_workers=cfg[ConfigValue.DATALOADER_WORKERS], pin_memory=cfg[ConfigValue.PIN_DATA_MEMORY] or torch.cuda.is_available())
         if self.world > 1:
