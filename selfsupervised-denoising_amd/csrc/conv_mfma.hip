@@ -63,6 +63,15 @@ static __device__ __forceinline__ unsigned fdiv(unsigned x, unsigned magic) { re
 static inline unsigned magic_of(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 static __device__ __forceinline__ unsigned magic_dev(unsigned d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 
+// ALLW (latency-bound layers that run as 32-channel blocks, 3x3): the whole [9 taps][32 rows][kc] weight block of a channel
+// chunk is staged together with the tile, ONE barrier, then all 9 taps x kc/16 K-steps run back to back -- instead of 9..27
+// pipeline steps of 6..12 MFMAs each separated by a barrier and a weight commit (a small layer's launch IS that chain).
+static __host__ __device__ inline bool conv_allw(const ssdn_conv_args& a, const ConvGeom& g, int mt, int kc) {
+    if (mt != 1 || a.ntaps != 9 || a.dst32) return false;
+    const size_t str = (size_t)kc * 2 + 16;
+    return (size_t)g.NP * str + 9u * 32u * str <= 160u * 1024u;
+}
+
 struct ConvAux {  // host-computed helpers passed by value
     unsigned mg_hw, mg_hh;  // magic reciprocals of HW and HH
     unsigned mg_ntaps;      // magic reciprocal of ntaps
@@ -71,6 +80,7 @@ struct ConvAux {  // host-computed helpers passed by value
     int ablate;             // tuning aid (env SSDN_CONV_ABLATE): 1 no MFMA, 2 no tile staging, 4 no weight stream, 8 no stores
     unsigned long long* trace;   // tuning aid (ssdn_debug_set_trace): 32 s_memtime stamps per workgroup, or NULL
     int desync;             // first-round workgroups start (hash(block) & 7) * desync * 8128 cycles late (0 = off)
+    int allw;               // all taps' weights of a channel chunk resident in LDS: no per-step weight stream / barriers
 };
 
 static unsigned long long* g_conv_trace = nullptr;
@@ -171,7 +181,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     half8 wrA[NW], wrB[NW], wrC[NW];    // three register sets: the weight stream runs THREE steps ahead of the MFMA work
     // every workgroup walks the taps in a different rotation: all workgroups of a launch stream the SAME 166 KB of weights,
     // and in lock-step they would all hit the same few L2 channels with the same 9 KB slice at the same moment
-    const int rot = (x.ablate & 64) ? 0 : (int)(wg_tile % (unsigned)a.ntaps);
+    const int rot = ((x.ablate & 64) || x.allw) ? 0 : (int)(wg_tile % (unsigned)a.ntaps);
     auto tap_of = [&](int tseq) { int t = tseq + rot; return t >= a.ntaps ? t - a.ntaps : t; };
     auto w_issue = [&](half8 (&wr)[NW], int step) {
         step = step < nsteps ? step : nsteps - 1;      // past the end: re-load the last slice (never committed)
@@ -290,6 +300,36 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         stamp();
     };
 
+    if (x.allw) {
+        // ---- ALLW: per channel chunk, stage tile + all nine weight slices, one barrier, 9 x KS K-steps barrier-free ----
+        const int wtotal = a.ntaps * WROWS * CC8;                    // 16-byte pieces of one chunk's weight block
+        for (int ch = 0; ch < nchunks; ++ch) {
+            if (ch > 0) __syncthreads();
+            for (int e0 = tid; e0 < wtotal; e0 += 8 * CONV_THREADS) {
+                half8 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * CONV_THREADS;
+                    const int ee = e < wtotal ? e : 0;
+                    const int t = ee / (WROWS * CC8), r = ee - t * (WROWS * CC8), m = r / CC8, cc = r - m * CC8;
+                    v[u] = ld_h8(wp + ((long long)t * a.Mpad + x.m_base + m) * a.Ktot + ch * KC + cc * 8);
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int e = e0 + u * CONV_THREADS;
+                    if (e < wtotal) {
+                        const int t = e / (WROWS * CC8), r = e - t * (WROWS * CC8), m = r / CC8, cc = r - m * CC8;
+                        *reinterpret_cast<half8*>(wl0 + t * WBUF + m * STR + cc * 16) = v[u];
+                    }
+                }
+            }
+            stage_tile(ch);
+            __syncthreads();
+            for (int t = 0; t < a.ntaps; ++t) compute(wl0 + t * WBUF, ch * a.ntaps + t);
+        }
+        __syncthreads();
+        stamp();
+    } else {
     // buffers alternate wl0 / wl1 by step parity; register sets rotate A, B, C by step mod 3.
     // invariant at the top of step s: LDS buffer s&1 holds W(s); W(s+1), W(s+2) are in flight in their register sets.
     if (x.desync && blockIdx.x < 512) {
@@ -329,6 +369,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         w_issue(wrC, step + 8);
         compute(wl1, step + 5);
         advance(wrA, wl0, step + 5);
+    }
     }
 
     if (x.ablate & 16) return;
@@ -522,6 +563,7 @@ static int conv_validate(const ssdn_conv_args* a) {
 
 static size_t conv_lds(const ssdn_conv_args* a, const ConvGeom& g, int mt) {
     size_t main_b = (conv_async(*a, a->kc) ? 2 * (size_t)g.NP * a->kc * 2 : (size_t)g.NP * g.PSTR) + 2 * (size_t)mt * 32 * g.WSTR;
+    if (conv_allw(*a, g, mt, a->kc) && !conv_async(*a, a->kc)) main_b = (size_t)g.NP * g.PSTR + 9 * (size_t)32 * g.WSTR;
     size_t epi_b = a->dst32 ? 0 : (size_t)(g.TN * g.TH * g.TW) * (mt * 64 + 16) + mt * 32 * 4;
     return main_b > epi_b ? main_b : epi_b;
 }
@@ -557,6 +599,8 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     double bytes = px * (a->c0 * 2.0 / (a->up0 ? 4.0 : 1.0) + a->c1 * 2.0) + px * m_real * (a->dst32 ? 4.0 : 2.0);
     prof_begin(3 - MT, s);
     x.nblk = nblk_y;
+    static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;      // A/B aid, read once
+    x.allw = (!no_allw && conv_allw(*a, g, MT, a->kc) && !conv_async(*a, a->kc)) ? 1 : 0;
     const int grid_all = nblk_y > 1 ? ((grid + 7) / 8) * 8 * nblk_y : grid;
     hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid_all), dim3(CONV_THREADS), lds, s, *a, x);
     prof_end(3 - MT, s, flops, bytes);

@@ -162,10 +162,13 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True, cu
                         lds = max(lds, TN * TH * TW * (mt * 64 + 16) + mt * 128)
                     if lds > budget:
                         continue
+                    # 32-channel-block layers: prefer a tiling whose whole 9-tap weight block fits next to the tile (k_conv ALLW:
+                    # one barrier per channel chunk instead of one per tap)
+                    allw = mt1 and len(taps) == 9 and NP * (kc * 2 + 16) + 9 * 32 * (kc * 2 + 16) <= LDS_LIMIT
                     halo = NP / float(TN * TH * TW)
                     # prefer: high utilisation, then 2 workgroups per CU, then large channel chunks (fewer barriers),
                     # then small halo, then wide tiles
-                    key = (round(util, 3), mt1 or (lds <= CONV_LDS_PREFERRED and kc >= min(48, Ktot)), kc, -round(halo, 3), ltw)
+                    key = (round(util, 3), mt1 or (lds <= CONV_LDS_PREFERRED and kc >= min(48, Ktot)), allw, kc, -round(halo, 3), ltw)
                     if best is None or key > best[0]:
                         best = (key, (ltw, lth, ltn, kc))
     if best is None:
