@@ -105,5 +105,9 @@ int conv_lds_bytes(const ssdn_conv_args* a);
 bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size);
 int conv_dma_lds_bytes(int mt);
 int launch_conv_dma(const ssdn_conv_args* a, hipStream_t s);
+// gemm_dma.hip: 1x1 layers with 96 / 384 output channels as a one-pass LDS-DMA GEMM
+bool gemm_dma_eligible(const ssdn_conv_args* a);
+int gemm_dma_lds_bytes(const ssdn_conv_args* a);
+int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s);
 extern "C" int ssdn_device_cus(void);
 int wgrad_lds_bytes(const ssdn_wgrad_args* a);

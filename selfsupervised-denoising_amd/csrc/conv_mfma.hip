@@ -542,6 +542,7 @@ extern "C" int ssdn_conv_set_mode(int mode) {
     return 0;
 }
 static bool conv_use_dma(const ssdn_conv_args* a) { return g_conv_mode > 0 && conv_dma_eligible(a, g_conv_mode == 2); }
+static bool conv_use_gemm(const ssdn_conv_args* a) { return g_conv_mode > 0 && gemm_dma_eligible(a); }
 
 static int conv_validate(const ssdn_conv_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("conv: ntaps out of range");
@@ -570,6 +571,7 @@ static size_t conv_lds(const ssdn_conv_args* a, const ConvGeom& g, int mt) {
 
 int conv_lds_bytes(const ssdn_conv_args* a) {
     if (conv_validate(a)) return -1;
+    if (conv_use_gemm(a)) return gemm_dma_lds_bytes(a);
     if (conv_use_dma(a)) return conv_dma_lds_bytes(a->Mpad >= 96 ? 3 : a->Mpad / 32);
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     int mt = a->Mpad / 32;
@@ -626,6 +628,7 @@ static int conv_launch_ks(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
 int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     int rc = conv_validate(a);
     if (rc) return rc;
+    if (conv_use_gemm(a)) return launch_gemm_dma(a, s);
     if (conv_use_dma(a)) return launch_conv_dma(a, s);
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     ConvAux x;

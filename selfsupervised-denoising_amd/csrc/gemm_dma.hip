@@ -1,0 +1,285 @@
+// SSDN_OP_CONV, 1x1 layers (the posterior head's NiN convolutions, noise_network.py:116-130 of the reference, and their data
+// gradients): out[p][m] = epi( sum_k in[p][k] * w[m][k] + bias[m] ) over P = N*H*W pixels -- a plain GEMM whose roofline is
+// HBM (every input pixel read once, every output written once: output_block.0 at batch 32 moves 2 x 100 MB for 38.6 GFLOP), so
+// the design goal is ONE pass over the input:
+//
+//   * a workgroup owns 256 consecutive pixels and ALL output channels of the layer (384: tile 256 x 384, eight waves of
+//     64 px x 192 ch = 12 accumulator tiles of 32x32; 96: eight waves of 32 px x 96 ch), so the activation tensor is fetched
+//     exactly once; the weight matrix (<= 288 KiB) streams from L2.
+//   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), 32 input channels per chunk: rows of 64 bytes, three
+//     stages in flight, one barrier per chunk.  A DMA instruction deposits 64 lanes x 16 B linearly, but every lane fetches from
+//     its own global address -- the 16-byte piece p of row r is stored at piece p ^ ((r >> 2) & 3), which makes every
+//     ds_read_b128 fragment read (32 rows x one K half) conflict-free (16-lane groups hit 16 distinct 16-byte slots).
+//   * per chunk a wave issues 2 x (WP + WM) ds_read_b128 and 2 x WP x WM MFMAs (32x32x16): 16 reads / 24 MFMAs for the 384 tile.
+//   * epilogue as in k_cdma: accumulators (initialised with the bias) -> LeakyReLU -> 16-bit, widened to 16-byte pieces with
+//     v_permlane32_swap, transposed through a wave-private LDS region, stored as pixel-contiguous runs; the data-gradient role
+//     multiplies by LeakyReLU'(saved activation) on the way out.
+#include "common.h"
+
+namespace {
+
+struct GdAux {
+    int nch;      // Ktot / 32
+    int ntiles;   // pixel tiles of TP
+};
+
+__device__ __forceinline__ void gd_dma16(unsigned lds_addr, int voff, u32x4_t rs, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+template <bool BF>
+__device__ __forceinline__ f32x16 gd_mma(half8 av, half8 bv, f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+}
+
+constexpr int GD_DA = 5, GD_DB = 3;
+
+// wait until all but the newest n groups of PER DMA instructions of this wave have landed
+template <int PER>
+__device__ __forceinline__ void gd_wait_groups(int n) {
+    static_assert(3 * PER < 64, "vmcnt immediate");
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+}
+
+}  // namespace
+
+// wave grid NWP (pixels) x NWM (channels); a wave owns WP x 32 pixels and WM x 32 output channels.  EPI bit 0: LeakyReLU' mask
+template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
+__global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, GdAux x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = NWP * NWM, TP = NWP * WP * 32, TM = NWM * WM * 32;
+    constexpr int ABYTES = TP * 64, BBYTES = TM * 64;
+    constexpr int DA = GD_DA, DB = GD_DB;                    // ring depths: activation chunks (HBM latency) / weight chunks (L2)
+    constexpr int NLA = NW / 2, NLB = NW - NLA;              // loader roles: waves [0, NLA) fetch activations, the rest weights --
+                                                             // vmcnt completes in order per WAVE, so the deep activation
+                                                             // prefetch must not share a counter with the shallow weight stream
+    constexpr int NIA = TP / 16, NIB = TM / 16, PA = (NIA + NLA - 1) / NLA, PB = (NIB + NLB - 1) / NLB;
+    constexpr int BOFF = DA * ABYTES, BIAS_OFF = BOFF + DB * BBYTES, DUMMY_OFF = BIAS_OFF + TM * 4;
+    constexpr int OSTR = WM * 64 + 16, NEK = WM * 2, CPP = WM * 4;
+    constexpr bool HAS_MASK = (EPI & 1) != 0;
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w / NWM, wm = w - wp * NWM;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int pix0 = blockIdx.x * TP;
+
+    const unsigned long long ap = (unsigned long long)a.src0.p, wgp = (unsigned long long)a.w;
+    const u32x4_t rs_a = {(unsigned)ap, (unsigned)(ap >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const u32x4_t rs_w = {(unsigned)wgp, (unsigned)(wgp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+
+    // DMA lane constants: lane -> (row lane >> 2 of a 16-row instruction, LDS piece lane & 3); the piece fetched is the swizzled one
+    const int drow = lane >> 2, dpiece = (lane & 3) ^ ((drow >> 2) & 3);
+    const int voffA = (drow * a.src0.cs + dpiece * 8) * 2;
+    const int voffB = (drow * a.Ktot + dpiece * 8) * 2;
+    const int sA0 = ((pix0 * a.src0.cs) + a.src0.co) * 2;
+    const bool loadA = w < NLA;
+    auto issueA = [&](int c, int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < PA; ++u) {
+            const int i = w + NLA * u;              // wave-uniform
+            if (i < NIA) {
+                const int soff = __builtin_amdgcn_readfirstlane(sA0 + (i * 16 * a.src0.cs + c * 32) * 2);
+                gd_dma16(lds0 + st * ABYTES + i * 1024, voffA, rs_a, soff);
+            } else {
+                // keep every loader's DMA count per chunk equal (one vmcnt immediate per role): an out-of-range fetch that
+                // drops zeros into a scratch KiB
+                gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+            }
+        }
+    };
+    auto issueB = [&](int c, int st) __attribute__((always_inline)) {
+#pragma unroll
+        for (int u = 0; u < PB; ++u) {
+            const int j = (w - NLA) + NLB * u;
+            if (j < NIB) {
+                const int soff = __builtin_amdgcn_readfirstlane((j * 16 * a.Ktot + c * 32) * 2);
+                gd_dma16(lds0 + BOFF + st * BBYTES + j * 1024, voffB, rs_w, soff);
+            } else {
+                gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+            }
+        }
+    };
+
+    if (loadA) {
+        for (int c = 0; c < DA - 1 && c < x.nch; ++c) issueA(c, c);
+    } else {
+        for (int c = 0; c < DB - 1 && c < x.nch; ++c) issueB(c, c);
+    }
+    float* bl = reinterpret_cast<float*>(smem + BIAS_OFF);
+    if (tid < TM) bl[tid] = (a.bias && tid < a.M) ? a.bias[tid] : 0.f;
+    __syncthreads();
+
+    f32x16 acc[WM][WP];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *reinterpret_cast<const float4*>(bl + (wm * WM + mt) * 32 + 8 * g + 4 * kh);
+#pragma unroll
+            for (int pt = 0; pt < WP; ++pt) {
+                acc[mt][pt][4 * g + 0] = b4.x; acc[mt][pt][4 * g + 1] = b4.y; acc[mt][pt][4 * g + 2] = b4.z; acc[mt][pt][4 * g + 3] = b4.w;
+            }
+        }
+
+    // fragment addresses: row l31 of a 32-row block, K half kh of K-step s -> piece (2s + kh) ^ ((l31 >> 2) & 3)
+    const int sw = (l31 >> 2) & 3;
+    const int fr0 = l31 * 64 + ((kh ^ sw) << 4), fr1 = l31 * 64 + (((2 + kh) ^ sw) << 4);
+    const int pbase = wp * WP * 2048, mbase = BOFF + wm * WM * 2048;
+
+    auto compute = [&](int sa, int sb_) __attribute__((always_inline)) {
+        const char* pa = smem + sa * ABYTES + pbase;
+        const char* pb = smem + sb_ * BBYTES + mbase;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int fr = s ? fr1 : fr0;
+            half8 pq[WP], wq[WM];
+#pragma unroll
+            for (int pt = 0; pt < WP; ++pt) pq[pt] = *reinterpret_cast<const half8*>(pa + pt * 2048 + fr);
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt) wq[mt] = *reinterpret_cast<const half8*>(pb + mt * 2048 + fr);
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int pt = 0; pt < WP; ++pt) acc[mt][pt] = gd_mma<BF>(wq[mt], pq[pt], acc[mt][pt]);
+        }
+    };
+
+    // ---- main loop: chunk c sits in activation stage c % DA and weight stage c % DB; a loader keeps D-1 chunks ahead ----
+    int ca = 0, cb = 0;                 // stages of chunk c
+    int ia = DA - 1, ib = DB - 1;       // stages the loaders fill next (chunk c + D - 1)
+    for (int c = 0; c < x.nch; ++c) {
+        const int left = x.nch - 1 - c;
+        if (loadA) gd_wait_groups<PA>(left < DA - 2 ? left : DA - 2);
+        else gd_wait_groups<PB>(left < DB - 2 ? left : DB - 2);
+        __syncthreads();
+        if (loadA) { if (c + DA - 1 < x.nch) issueA(c + DA - 1, ia); }
+        else { if (c + DB - 1 < x.nch) issueB(c + DB - 1, ib); }
+        compute(ca, cb);
+        ca = ca == DA - 1 ? 0 : ca + 1; ia = ia == DA - 1 ? 0 : ia + 1;
+        cb = cb == DB - 1 ? 0 : cb + 1; ib = ib == DB - 1 ? 0 : ib + 1;
+    }
+    __syncthreads();      // every wave is done with the stages: they become the epilogue's transpose regions
+
+    const float slope = a.act ? LRELU_SLOPE : 1.f;
+    char* reg = smem + w * (32 * OSTR);
+#pragma unroll
+    for (int pt = 0; pt < WP; ++pt) {
+        const int pix_p = pix0 + (wp * WP + pt) * 32;
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) {
+                unsigned pk[2][2];
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float v[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        v[j] = acc[mt][pt][(2 * gp + h) * 4 + j];
+                        v[j] = fmaxf(v[j], slope * v[j]);
+                    }
+                    pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
+                    pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
+                }
+                u32x4_t o;
+#pragma unroll
+                for (int d = 0; d < 2; ++d) {
+                    auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+                    o[d] = r[0]; o[2 + d] = r[1];
+                }
+                const int piece = mt * 4 + 2 * gp + kh;
+                *reinterpret_cast<u32x4_t*>(reg + l31 * OSTR + piece * 16) = o;
+            }
+        // LDS -> HBM: 32 pixels x CPP 16-byte pieces, pixel-contiguous
+#pragma unroll
+        for (int k0 = 0; k0 < NEK; k0 += 6) {
+            u32x4_t mb[6];
+            int goff[6], loff[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                const int p = (k0 + k) * 64 + lane;
+                const int px = p / CPP, c16 = (p - px * CPP) << 4;
+                const int pix = pix_p + px;
+                loff[k] = px * OSTR + c16;
+                goff[k] = (pix * a.dst.cs + a.dst.co + wm * WM * 32) * 2 + c16;
+                if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + wm * WM * 32) * 2 + c16, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) {
+                u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + loff[k]);
+                if constexpr (HAS_MASK) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v0, v1;
+                        if constexpr (BF) { v0 = bf_lo(o[q]); v1 = bf_hi(o[q]); }
+                        else { v0 = f16_lo(o[q]); v1 = f16_hi(o[q]); }
+                        const int mlo = (int)(short)(mb[k][q] & 0xffffu), mhi = (int)mb[k][q] >> 16;
+                        v0 *= mlo > 0 ? 1.f : LRELU_SLOPE;
+                        v1 *= mhi > 0 ? 1.f : LRELU_SLOPE;
+                        o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
+                    }
+                }
+                __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+            }
+        }
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------------------
+bool gemm_dma_eligible(const ssdn_conv_args* a) {
+    if (a->ntaps != 1 || a->dy[0] || a->dx[0] || a->up0 || a->c1 || a->src1.p || a->dst32 || a->add.p) return false;
+    if (a->c0 != a->Ktot || a->Ktot % 32) return false;
+    if (a->M != a->Mpad || (a->Mpad != 384 && a->Mpad != 96)) return false;
+    const long long px = (long long)a->N * a->H * a->W;
+    if (px % 256) return false;
+    if (!a->bf16 && a->mask.p) return false;
+    int csmax = a->dst.cs > a->src0.cs ? a->dst.cs : a->src0.cs;
+    csmax = csmax > a->mask.cs ? csmax : a->mask.cs;
+    if (px * csmax * 2 >= (1ll << 31)) return false;
+    if ((a->src0.co & 7) || (a->src0.cs & 7)) return false;
+    return true;
+}
+
+int gemm_dma_lds_bytes(const ssdn_conv_args* a) { const int tm = a->Mpad == 384 ? 384 : 96; return GD_DA * 256 * 64 + GD_DB * tm * 64 + tm * 4 + 1024; }
+
+template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
+static int gd_launch(const ssdn_conv_args* a, hipStream_t s) {
+    constexpr int TP = NWP * WP * 32, TM = NWM * WM * 32;
+    constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + TM * 4 + 1024;
+    static_assert(TP == 256, "gemm_dma_lds_bytes assumes 256-pixel tiles");
+    static_assert(NWP * NWM * 32 * (WM * 64 + 16) <= GD_DA * TP * 64 + GD_DB * TM * 64, "epilogue regions must fit in the rings");
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_gdma<WP, WM, NWP, NWM, BF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    GdAux x;
+    x.nch = a->Ktot / 32;
+    const double px = (double)a->N * a->H * a->W;
+    x.ntiles = (int)(px / TP);
+    const int kreal = a->kreal > 0 ? a->kreal : a->Ktot;
+    prof_begin(0, s);
+    hipLaunchKernelGGL((k_gdma<WP, WM, NWP, NWM, BF, EPI>), dim3(x.ntiles), dim3(64 * NWP * NWM), LDS, s, *a, x);
+    prof_end(0, s, 2.0 * px * a->M * kreal, px * (a->c0 + a->M) * 2.0);
+    SSDN_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s) {
+    const int epi = a->mask.p ? 1 : 0;
+    if (a->Mpad == 384) {
+        if (!a->bf16) return gd_launch<2, 6, 4, 2, false, 0>(a, s);
+        return epi ? gd_launch<2, 6, 4, 2, true, 1>(a, s) : gd_launch<2, 6, 4, 2, true, 0>(a, s);
+    }
+    if (!a->bf16) return gd_launch<1, 3, 8, 1, false, 0>(a, s);
+    return epi ? gd_launch<1, 3, 8, 1, true, 1>(a, s) : gd_launch<1, 3, 8, 1, true, 0>(a, s);
+}
