@@ -379,6 +379,11 @@ int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* f
  * its shape class with at least one 256-pixel tile per CU; 2 = k_cdma for every layer of its shape class (test aid). */
 int ssdn_conv_set_mode(int mode);
 
+/* ssdn_run_ops executes a run of consecutive SSDN_OP_WGRAD ops on one lane as ONE launch (k_wgrad_multi) when every op of the
+ * run is "mergeable": at most 32768 pixels (the layers at the bottom of the U), mblocks <= 1, and a tiling the merged kernel
+ * carries an instance for.  The result is bit-identical to one launch per op.  Returns 1 if `a` is mergeable, else 0. */
+int ssdn_wgrad_mergeable(const ssdn_wgrad_args* a);
+
 /* Tuning aid (tools/conv_bench.py): device buffer that receives 32 s_memtime stamps per workgroup of the MFMA kernels, or
  * NULL (default) for none. */
 void ssdn_debug_set_trace(void* device_buffer);

@@ -136,6 +136,7 @@ int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* f
 
 int ssdn_conv_lds_bytes(const ssdn_conv_args* a) { return conv_lds_bytes(a); }
 int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a) { return wgrad_lds_bytes(a); }
+int ssdn_wgrad_mergeable(const ssdn_wgrad_args* a) { return a && wgrad_mergeable(a) ? 1 : 0; }
 
 #define SSDN_NEVENTS 256
 #define SSDN_NLANES 4
@@ -199,7 +200,17 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_UPSUM_BWD: rc = launch_upsum_bwd((const ssdn_upsum_args*)p, s); break;
             case SSDN_OP_UNROT_FWD: rc = launch_unrot_fwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_UNROT_BWD: rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
-            case SSDN_OP_WGRAD: rc = launch_wgrad((const ssdn_wgrad_args*)p, s); break;
+            case SSDN_OP_WGRAD: {   // a run of consecutive small-layer weight-gradient GEMMs on the same lane is one launch
+                static const bool no_merge = getenv("SSDN_NO_WGRAD_MERGE") != nullptr;      // A/B aid, read once
+                const ssdn_wgrad_args* items[WGRAD_MULTI_MAX];
+                int m = 0;
+                while (!no_merge && m < WGRAD_MULTI_MAX && i + m < n && ops[i + m].type == SSDN_OP_WGRAD && ops[i + m].args &&
+                       (one_lane ? 0 : ops[i + m].lane) == lane && wgrad_mergeable((const ssdn_wgrad_args*)ops[i + m].args))
+                    items[m] = (const ssdn_wgrad_args*)ops[i + m].args, ++m;
+                if (m > 1) { rc = launch_wgrad_multi(items, m, s); i += m - 1; }
+                else rc = launch_wgrad((const ssdn_wgrad_args*)p, s);
+                break;
+            }
             case SSDN_OP_WREDUCE: {   // a run of consecutive reductions on the same lane is two launches in total
                 const ssdn_wreduce_args* items[WREDUCE_MULTI_MAX];
                 int m = 0;

@@ -81,6 +81,8 @@ void prof_end(int kind, hipStream_t s, double flops, double bytes);
 // launchers implemented in the individual .hip files; all return 0 / negative error
 int launch_conv(const ssdn_conv_args* a, hipStream_t s);
 int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s);
+bool wgrad_mergeable(const ssdn_wgrad_args* a);                 // small layer with a k_wgrad_multi instance
+int launch_wgrad_multi(const ssdn_wgrad_args* const* items, int n, hipStream_t s);
 int launch_pack_input(const ssdn_pack_input_args* a, hipStream_t s);
 int launch_pool_fwd(const ssdn_pool_args* a, hipStream_t s);
 int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s);
@@ -92,6 +94,7 @@ int launch_wpack(const ssdn_wpack_args* a, hipStream_t s);
 #define WPACK_MULTI_MAX 24
 int launch_wpack_multi(const ssdn_wpack_args* const* items, int n, hipStream_t s);
 #define WREDUCE_MULTI_MAX 32
+#define WGRAD_MULTI_MAX 32
 int launch_wreduce_multi(const ssdn_wreduce_args* const* items, int n, hipStream_t s);
 int launch_grad_pack(const ssdn_grad_pack_args* a, hipStream_t s);
 int launch_head(const ssdn_head_args* a, hipStream_t s);

@@ -14,6 +14,11 @@
 // tiles.  At the end every workgroup writes its accumulators to its own fp32 slab (plain coalesced stores, no atomics) and
 // SSDN_OP_WREDUCE sums the slabs in a fixed order => bit-reproducible gradients.
 #include "common.h"
+#include <algorithm>
+#include <cstring>
+#include <mutex>
+#include <utility>
+#include <vector>
 #include <type_traits>
 
 template <int I, int N, class F>
@@ -140,8 +145,10 @@ static __device__ __forceinline__ void mma_bf16(f32x16& c, half8 av, half8 bv) {
 // (pixel-in-row, channel chunk) -> global byte offset and LDS byte offset is computed ONCE per kernel.  The rows of a tile are
 // dealt to the 4 waves; a wave issues one row item per K-step (BOTH: one input and one dZ row) and writes it to the other
 // LDS image two K-steps later.
+// (the body is a device function of the launch coordinates (bx, by, gdx) = (blockIdx.x, blockIdx.y, gridDim.x) so that
+//  k_wgrad_multi can run the workgroups of SEVERAL layers' weight-gradient GEMMs inside one launch)
 template <int MT, int CPW, int NL, bool BOTH, int PS, int KS, int RWX, int RWD>
-__global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x) {
+static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, const WgAux& x, const unsigned bx, const unsigned by, const unsigned gdx) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr bool SPLIT = MT * CPW > 16;         // accumulators do not fit the AGPR file
     const WgGeom g = wg_geom(a);
@@ -152,11 +159,11 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     // Workgroup -> (pixel partition = slab index, block of M output channels).  Workgroups go to the 8 XCDs round-robin by
     // id and every XCD has its own L2: the mblocks workgroups of one pixel partition get ids 8 apart, i.e. the same XCD,
     // dispatched back to back -- they stream the same tiles in lock-step and share them through L2.
-    int wg_slab = blockIdx.x, wg_nslabs = gridDim.x, wg_mb = 0;
+    int wg_slab = bx, wg_nslabs = gdx, wg_mb = 0;
     if (a.mblocks > 1) {
-        const unsigned j = blockIdx.x >> 3;
+        const unsigned j = bx >> 3;
         wg_mb = (int)(j % (unsigned)a.mblocks);
-        wg_slab = (int)(j / (unsigned)a.mblocks) * 8 + (int)(blockIdx.x & 7);
+        wg_slab = (int)(j / (unsigned)a.mblocks) * 8 + (int)(bx & 7);
         wg_nslabs = a.nslabs;
         if (wg_slab >= a.nslabs) return;      // (grid is rounded up to a multiple of 8 partitions)
     }
@@ -171,7 +178,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     bool ct_on[CPW], ct_bias[CPW];
 #pragma unroll
     for (int j = 0; j < CPW; ++j) {
-        const int ct = blockIdx.y * (WG_WAVES * CPW) + wave + WG_WAVES * j;
+        const int ct = by * (WG_WAVES * CPW) + wave + WG_WAVES * j;
         ct_on[j] = ct <= CT;
         ct_bias[j] = ct == 0;
         const int wt = ct_on[j] && !ct_bias[j] ? ct - 1 : 0;
@@ -217,7 +224,7 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
 
     int tr_i = 0;
     auto stamp = [&]() {
-        if (x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
+        if (x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)bx * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
     };
     stamp();
     // ---- double-buffered pipeline over this workgroup's tiles -------------------------------------------------------
@@ -602,6 +609,41 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x
     }
 }
 
+template <int MT, int CPW, int NL, bool BOTH, int PS, int KS, int RWX, int RWD>
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad(ssdn_wgrad_args a, WgAux x) {
+    wgrad_body<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>(a, x, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// ---- several layers' weight-gradient GEMMs in ONE launch ------------------------------------------------------------------
+// The layers at the bottom of the U (16x16 pixels and below) have a few hundred tiles each: one launch per layer is a chain of
+// K-steps a handful of tiles long plus the slab write, on a chip it cannot fill -- 13 such launches are ~230 us of the
+// weight-gradient lane.  k_wgrad_multi runs the workgroups of a RUN of consecutive SSDN_OP_WGRAD ops (ssdn_run_ops merges
+// them when every op is in the instance set below) side by side: entry e owns blocks [first, first + gx*gy) of the grid and
+// executes exactly the code of its own launch (same template instance, same (bx, by, gdx)), so results are bit-identical.
+struct WgMultiEntry {
+    ssdn_wgrad_args a;
+    WgAux x;
+    int first, gx, gy, inst;
+};
+#define WG_MULTI_INSTANCES(X) \
+    X(0, 2, 1, 4, false) X(1, 2, 2, 4, false) X(2, 2, 3, 4, false) \
+    X(4, 3, 1, 4, false) X(5, 3, 2, 4, false) X(6, 3, 3, 4, false) \
+    X(9, 3, 1, 6, true) X(10, 2, 1, 6, true)
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_multi(const WgMultiEntry* __restrict__ tab, int n) {
+    int e = 0;
+    while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].first) ++e;
+    const WgMultiEntry& E = tab[e];
+    const unsigned local = blockIdx.x - (unsigned)E.first;
+    const unsigned gx = (unsigned)E.gx;
+    const unsigned by = local / gx, bx = local - by * gx;
+    switch (E.inst) {
+#define WG_X(id, mt, cpw, nl, both) case id: wgrad_body<mt, cpw, nl, both, 0, 0, 0, 0>(E.a, E.x, bx, by, gx); break;
+        WG_MULTI_INSTANCES(WG_X)
+#undef WG_X
+        default: break;
+    }
+}
+
 static int wgrad_validate(const ssdn_wgrad_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("wgrad: ntaps out of range");
     if (a->ltw + a->lth + a->ltn > 8 || a->ltw + a->lth + a->ltn < 5) return ssdn_set_error("wgrad: tile must have 32..256 pixels");
@@ -664,20 +706,132 @@ static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& 
     return 0;
 }
 
-int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
+struct WgPrep { WgGeom g; WgAux x; WgItems wi; int MT, CPW, gx, gy; size_t lds; };
+static int wgrad_prepare(const ssdn_wgrad_args* a, WgPrep* p) {
     int rc = wgrad_validate(a);
     if (rc) return rc;
-    WgGeom g = wg_geom(*a);
-    WgAux x;
+    p->g = wg_geom(*a);
+    WgAux& x = p->x;
+    memset(&x, 0, sizeof(x));
     x.trace = (unsigned long long*)ssdn_debug_get_trace();
-    x.mg_hh = magic_ofw(g.HH);
+    x.mg_hh = magic_ofw(p->g.HH);
     x.ccx = a->Ktot / 8;
     x.ccd = a->M / 8;
     x.mg_ccx = magic_ofw(x.ccx);
     x.mg_ccd = magic_ofw(x.ccd);
-    const WgItems wi = wgrad_items(a, g);
-    if (wi.nl > 6) return ssdn_set_error("wgrad: the tile cannot be prefetched within its K-steps (too many rows / too wide rows)");
-    x.rswx = wi.rswx; x.rswd = wi.rswd;
+    p->wi = wgrad_items(a, p->g);
+    if (p->wi.nl > 6) return ssdn_set_error("wgrad: the tile cannot be prefetched within its K-steps (too many rows / too wide rows)");
+    x.rswx = p->wi.rswx; x.rswd = p->wi.rswd;
+    p->MT = a->Mpad / 32;
+    const int CT = a->ntaps * (a->Kpad / 32) + 1;
+    p->gy = a->csplit > 1 ? a->csplit : 1;
+    p->CPW = (CT + WG_WAVES * p->gy - 1) / (WG_WAVES * p->gy);   // column tiles per wave (gy = column groups)
+    p->gx = a->mblocks > 1 ? ((a->nslabs + 7) / 8) * 8 * a->mblocks : a->nslabs;
+    p->lds = 2 * ((size_t)p->g.XB + (size_t)p->g.DB) + WG_ONES_BYTES;
+    if (p->lds > 160 * 1024) return ssdn_set_error("wgrad: tiling needs %zu B of LDS (> 160 KiB)", p->lds);
+    return 0;
+}
+
+// instance of k_wgrad_multi that runs this op, or -1 (the op needs its own launch)
+static int wgrad_multi_inst(const WgPrep& p) {
+#define WG_X(id_, mt_, cpw_, nl_, both_) if (p.MT == mt_ && p.CPW == cpw_ && (p.wi.both != 0) == both_) return id_;
+    WG_MULTI_INSTANCES(WG_X)
+#undef WG_X
+    return -1;
+}
+bool wgrad_mergeable(const ssdn_wgrad_args* a) {
+    // layers of at most 128 images x 16 x 16 pixels: their own launch cannot fill the chip
+    if ((long long)a->N * a->H * a->W > 32768 || a->mblocks > 1) return false;
+    WgPrep p;
+    if (wgrad_validate(a)) return false;
+    p.g = wg_geom(*a);
+    p.wi = wgrad_items(a, p.g);
+    if (p.wi.nl > 6) return false;
+    p.MT = a->Mpad / 32;
+    const int CT = a->ntaps * (a->Kpad / 32) + 1;
+    p.gy = a->csplit > 1 ? a->csplit : 1;
+    p.CPW = (CT + WG_WAVES * p.gy - 1) / (WG_WAVES * p.gy);
+    return wgrad_multi_inst(p) >= 0;
+}
+
+namespace {
+struct WgMultiCache { std::vector<WgMultiEntry> host; WgMultiEntry* dev; int device; };
+std::vector<WgMultiCache> g_wg_multi_cache;      // device copies of the tables of the op-list runs seen so far (a handful per
+std::mutex g_wg_multi_mutex;                      // process: the op lists of an engine are static)
+}
+
+int launch_wgrad_multi(const ssdn_wgrad_args* const* items, int n, hipStream_t s) {
+    if (n < 1 || n > WGRAD_MULTI_MAX) return ssdn_set_error("wgrad: bad batch size %d", n);
+    std::vector<WgMultiEntry> tab((size_t)n);
+    memset(tab.data(), 0, sizeof(WgMultiEntry) * (size_t)n);
+    size_t lds = 0;
+    int blocks = 0;
+    double flops = 0, bytes = 0;
+    // heaviest workgroups first: blocks are dispatched in index order, so the short ones fill in behind the long ones
+    std::vector<std::pair<double, int>> order;
+    std::vector<WgPrep> preps((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        int rc = wgrad_prepare(items[i], &preps[i]);
+        if (rc) return rc;
+        const WgPrep& p = preps[i];
+        const double tiles_per_wg = (double)p.g.ntiles / (items[i]->nslabs > 0 ? items[i]->nslabs : 1);
+        const double cost = tiles_per_wg * (p.g.TN * p.g.TH * p.g.TW / 16) * (660.0 + 90.0 * p.CPW) +
+                            (double)items[i]->ntaps * items[i]->Mpad * items[i]->Kpad * 4.0 / 10.0 / p.gy;
+        order.push_back({-cost, i});
+    }
+    std::sort(order.begin(), order.end());
+    for (int k = 0; k < n; ++k) {
+        const int i = order[k].second;
+        const WgPrep& p = preps[i];
+        WgMultiEntry& e = tab[k];
+        memcpy(&e.a, items[i], sizeof(ssdn_wgrad_args));
+        e.x = p.x;
+        e.inst = wgrad_multi_inst(p);
+        if (e.inst < 0) return ssdn_set_error("wgrad: op %d of a merged run has no k_wgrad_multi instance (MT=%d CPW=%d both=%d)", i, p.MT, p.CPW, p.wi.both);
+        e.first = blocks; e.gx = p.gx; e.gy = p.gy;
+        blocks += p.gx * p.gy;
+        lds = p.lds > lds ? p.lds : lds;
+        const double px = (double)items[i]->N * items[i]->H * items[i]->W;
+        flops += 2.0 * px * items[i]->M * items[i]->Ktot * items[i]->ntaps;
+        bytes += px * 2.0 * (items[i]->M + items[i]->Ktot);
+    }
+    int dev = 0;
+    SSDN_CHECK_HIP(hipGetDevice(&dev));
+    WgMultiEntry* dtab = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_wg_multi_mutex);
+        for (const WgMultiCache& c : g_wg_multi_cache)
+            if (c.device == dev && c.host.size() == tab.size() && !memcmp(c.host.data(), tab.data(), sizeof(WgMultiEntry) * tab.size())) { dtab = c.dev; break; }
+        if (!dtab) {
+            if (g_wg_multi_cache.size() >= 64) {          // bounded: drop the oldest table (no launch that uses it can still be
+                SSDN_CHECK_HIP(hipDeviceSynchronize());   // queued after the synchronisation)
+                SSDN_CHECK_HIP(hipFree(g_wg_multi_cache.front().dev));
+                g_wg_multi_cache.erase(g_wg_multi_cache.begin());
+            }
+            SSDN_CHECK_HIP(hipMalloc((void**)&dtab, sizeof(WgMultiEntry) * tab.size()));
+            SSDN_CHECK_HIP(hipMemcpy(dtab, tab.data(), sizeof(WgMultiEntry) * tab.size(), hipMemcpyHostToDevice));
+            g_wg_multi_cache.push_back({tab, dtab, dev});
+        }
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    prof_begin(SSDN_PROF_WGRAD, s);
+    hipLaunchKernelGGL(k_wgrad_multi, dim3(blocks), dim3(WG_THREADS), lds, s, (const WgMultiEntry*)dtab, n);
+    prof_end(SSDN_PROF_WGRAD, s, flops, bytes);
+    SSDN_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
+    WgPrep prep;
+    int rc = wgrad_prepare(a, &prep);
+    if (rc) return rc;
+    const WgGeom& g = prep.g;
+    const WgAux& x = prep.x;
+    const WgItems& wi = prep.wi;
     const int MT = a->Mpad / 32;
     const int CT = a->ntaps * (a->Kpad / 32) + 1;
     const int gy = a->csplit > 1 ? a->csplit : 1;

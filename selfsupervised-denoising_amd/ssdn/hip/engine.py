@@ -109,19 +109,40 @@ class DeviceNet:
             return recs, [op.a.get("layer") if op.type == "wreduce" else None for op in plan.bwd]
         buckets = bucket_layers(plan.layers)
         bucket_of = {name: k for k, b in enumerate(buckets) for name in b}
+        # The weight-gradient GEMMs of the layers at 16x16 pixels and below are issued together, where the last of them
+        # stood: the executor runs a run of consecutive small SSDN_OP_WGRAD ops as ONE launch (k_wgrad_multi; same rule as
+        # csrc/wgrad_mfma.hip::wgrad_mergeable).  Legal for the same reason: a side-lane op may always be delayed.
+        small = lambda op: op.type == "wgrad" and op.a["N"] * op.a["H"] * op.a["W"] <= 32768 and not os.environ.get("SSDN_NO_WGRAD_GROUPS")  # noqa: E731
+        # (one run per gradient bucket, so that a bucket still completes where it did)
+        flush_at = {}                                   # index of the last small wgrad of each bucket
+        for i, op in enumerate(plan.bwd):
+            if small(op):
+                flush_at[bucket_of[op.a["layer"]]] = i
+        nsmall = {k: sum(1 for op in plan.bwd if small(op) and bucket_of[op.a["layer"]] == k) for k in flush_at}
+        flush_at = {k: i for k, i in flush_at.items() if nsmall[k] > 1}
+        grouped = lambda op: small(op) and bucket_of[op.a["layer"]] in flush_at  # noqa: E731
         last = {}
         for i, op in enumerate(plan.bwd):
             if op.type in ("wgrad", "wreduce"):
-                last[bucket_of[op.a["layer"]]] = i
+                k = bucket_of[op.a["layer"]]
+                last[k] = max(last.get(k, -1), flush_at[k] if grouped(op) else i)
         out, names, pending = [], [], {k: [] for k in range(len(buckets))}
+        pending_small = {k: [] for k in range(len(buckets))}
         for i, (op, rec) in enumerate(zip(plan.bwd, recs)):
             if op.type == "wreduce":
                 pending[bucket_of[op.a["layer"]]].append((rec, op.a["layer"]))
+            elif grouped(op):
+                pending_small[bucket_of[op.a["layer"]]].append(rec)
             else:
                 out.append(rec)
                 names.append(None)
-            for k, idx in last.items():
+            for k, idx in flush_at.items():
                 if idx == i:
+                    out += pending_small[k]
+                    names += [None] * len(pending_small[k])
+                    pending_small[k] = []
+            for k in sorted(last):
+                if last[k] == i:
                     for rec_k, name_k in pending[k]:
                         out.append(rec_k)
                         names.append(name_k)

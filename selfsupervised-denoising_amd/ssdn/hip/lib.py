@@ -122,7 +122,8 @@ ABI_VERSION = 4      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirro
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
-           "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode"]
+           "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
+           "ssdn_wgrad_mergeable"]
 PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3)
 
 _lib = None
@@ -162,6 +163,8 @@ def load() -> C.CDLL:
     lib.ssdn_profile_read.restype = C.c_int
     lib.ssdn_conv_set_mode.argtypes = [C.c_int]
     lib.ssdn_conv_set_mode.restype = C.c_int
+    lib.ssdn_wgrad_mergeable.argtypes = [C.c_void_p]
+    lib.ssdn_wgrad_mergeable.restype = C.c_int
     lib.ssdn_struct_size.argtypes = [C.c_int]
     lib.ssdn_struct_size.restype = C.c_int
     if lib.ssdn_abi_version() != ABI_VERSION:

@@ -369,3 +369,43 @@ def test_full_size_config2_properties():
             if not (_rel(a, rg) <= 0.15 and cos >= 0.99):
                 bad.append("%s.%s vs fp32 oracle: rel %.3e cos %.5f" % (l.name, nm, _rel(a, rg), cos))
     assert not bad, "\n".join(bad)
+
+
+def test_merged_weight_gradient_launch_is_bit_identical():
+    """A run of consecutive small-layer SSDN_OP_WGRAD ops executes as ONE launch (k_wgrad_multi, csrc/wgrad_mfma.hip); every
+    workgroup runs the code of its own layer's launch, so the slabs must equal those of one-op-at-a-time execution bit for bit."""
+    import ctypes as C
+    from ssdn.hip import lib as L
+    from ssdn.hip.engine import DeviceNet, OpList, current_stream
+    from ssdn.hip.graph import NetPlan
+    B, P = 2, 32
+    dev = torch.device("cuda:0")
+    plan = NetPlan("m/", 3, 9, True, B, P, P, cus=L.load().ssdn_device_cus())
+    g = torch.Generator(device="cpu").manual_seed(11)
+    flat = (torch.randn(plan.nparams, generator=g) * 0.05).to(dev)
+    dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+    for name, t in dn.t.items():
+        if t.dtype in (torch.float16, torch.bfloat16):
+            t.copy_((torch.randn(t.shape, generator=g) * 0.5).to(dev))
+    ops = [op for op in plan.bwd if op.type == "wgrad"]
+    assert len(ops) > 8
+    recs = [dn._mat(op) for op in ops]
+    red = OpList([dn._mat(op) for op in plan.bwd if op.type == "wreduce"])
+    dn.t["m/scale"].fill_(1.0)                                # (written by SSDN_OP_GRAD_PACK in a real backward pass)
+
+    def run(lists):
+        # (rows of padded output channels hold whatever the LDS held: compare what the reductions read -- the real rows)
+        dn.grads.fill_(float("nan"))
+        for ol in lists:
+            ol.run(current_stream())
+        red.run(current_stream())
+        torch.cuda.synchronize()
+        return dn.grads.clone()
+
+    one_by_one = run([OpList([r]) for r in recs])           # a run of one op is never merged
+    merged = run([OpList(recs)])
+    nmerge = sum(1 for r in recs if L.load().ssdn_wgrad_mergeable(C.byref(r[1])))
+    assert nmerge >= 8, "the fixture must exercise the merged launch (%d mergeable ops)" % nmerge
+    n = plan.nparams
+    assert torch.isfinite(one_by_one[:n]).all()
+    assert torch.equal(one_by_one[:n], merged[:n])
