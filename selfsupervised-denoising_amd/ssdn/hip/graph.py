@@ -308,6 +308,10 @@ class NetPlan:
         def candidate(G):
             cpw = -(-ctiles // (4 * G))
             cus_eff = max(1, self.cus // G)
+            if mblocks > 1 and not os.environ.get("SSDN_HEAD_FULL_SLABS"):
+                # the mblocks workgroups of a pixel partition run side by side: cus / mblocks partitions fill the chip in ONE
+                # round with 1/mblocks of the slab traffic (output_block.0: 38 MB instead of 151 MB written and read back)
+                cus_eff = max(1, self.cus // mblocks)
             tile, ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad, Ktot, Mz, cus_eff)
             ns = max(1, min(ntiles, cus_eff))
             ksteps = (1 << sum(tile)) // 16
