@@ -81,6 +81,7 @@ struct ConvAux {  // host-computed helpers passed by value
     unsigned long long* trace;   // tuning aid (ssdn_debug_set_trace): 32 s_memtime stamps per workgroup, or NULL
     int desync;             // first-round workgroups start (hash(block) & 7) * desync * 8128 cycles late (0 = off)
     int allw;               // all taps' weights of a channel chunk resident in LDS: no per-step weight stream / barriers
+    int flat;               // allw + the tile is 256 pixels of WHOLE images: flat staging / epilogue, register prefetch of chunk c+1
 };
 
 static unsigned long long* g_conv_trace = nullptr;
@@ -300,7 +301,181 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         stamp();
     };
 
+    bool flat_done = false;
+    if constexpr (MT == 1 && CONV_THREADS == 256 && KS <= 4) {
+    if (x.flat) {
+        // ---- FLAT ALLW (layers of whole-image tiles: 16x16 pixels and below) ------------------------------------------------
+        // The tile's 256 pixels are 256 CONSECUTIVE pixels of the NHWC tensors (whole images), so staging and the epilogue
+        // are flat loops with shift arithmetic; the halo ring is zeroed once (it never changes); chunk c+1 (tile + all nine
+        // weight slices, 13..26 16-byte loads per thread) is prefetched into registers while chunk c is on the matrix cores.
+        // These launches are chains of dependent latencies (a handful of workgroups): before, 2-3 exposed load batches per
+        // chunk, a bias round trip and a row-by-row epilogue made a 2x2-pixel layer cost 43 K cycles for 1.7 K cycles of MFMA.
+        stamp();
+        constexpr int NWQ = (9 * WROWS * CC8 + CONV_THREADS - 1) / CONV_THREADS;
+        constexpr int wtotal = 9 * WROWS * CC8;
+        half8 pw[NWQ], pt[CC8];
+        const int lhw = a.ltw + a.lth;
+        const long long pixb = (long long)n0 << lhw;               // first pixel of the tile (TW == W, TH == H)
+        auto issue_chunk = [&](int ch) __attribute__((always_inline)) {
+#pragma unroll
+            for (int i = 0; i < NWQ; ++i) {
+                const int e = tid + i * CONV_THREADS;
+                const int ee = e < wtotal ? e : 0;
+                const int t = ee / (WROWS * CC8), r = ee - t * (WROWS * CC8), m = r / CC8, cc = r - m * CC8;
+                pw[i] = ld_h8(wp + ((long long)t * a.Mpad + x.m_base + m) * a.Ktot + ch * KC + cc * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < CC8; ++u) {
+                const int f = tid + u * CONV_THREADS;
+                const int q = f / CC8, cc = f - q * CC8;
+                const int tn = q >> lhw;
+                const int k = ch * KC + cc * 8;
+                pt[u] = zero_h8();
+                if (n0 + tn < a.N) {
+                    if (k < a.c0) {
+                        if (a.up0) {
+                            const int ty = (q >> a.ltw) & (g.TH - 1), tx = q & (g.TW - 1);
+                            pt[u] = ld_h8(s0 + ((((long long)(n0 + tn) * H0 + (ty >> 1)) * W0 + (tx >> 1)) * a.src0.cs + a.src0.co + k));
+                        } else {
+                            pt[u] = ld_h8(s0 + ((pixb + q) * a.src0.cs + a.src0.co + k));
+                        }
+                    } else {
+                        pt[u] = ld_h8(s1 + ((pixb + q) * a.src1.cs + a.src1.co + (k - a.c0)));
+                    }
+                }
+            }
+        };
+        issue_chunk(0);
+        float bias_r = 0.f;
+        if (tid < WROWS && a.bias && x.m_base + tid < a.M) bias_r = a.bias[x.m_base + tid];
+        for (int z = tid * 16; z < tbytes; z += CONV_THREADS * 16) *reinterpret_cast<half8*>(tile + z) = zero_h8();
+        __syncthreads();
+        for (int ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+            for (int i = 0; i < NWQ; ++i) {
+                const int e = tid + i * CONV_THREADS;
+                if (e < wtotal) {
+                    const int t = e / (WROWS * CC8), r = e - t * (WROWS * CC8), m = r / CC8, cc = r - m * CC8;
+                    *reinterpret_cast<half8*>(wl0 + t * WBUF + m * STR + cc * 16) = pw[i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < CC8; ++u) {
+                const int f = tid + u * CONV_THREADS;
+                const int q = f / CC8, cc = f - q * CC8;
+                const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> lhw;
+                *reinterpret_cast<half8*>(tile + ((tn * g.HH + ty + g.padT) * g.HW + tx + g.padL) * tstr + cc * 16) = pt[u];
+            }
+            __syncthreads();
+            stamp();
+            if (ch + 1 < nchunks) issue_chunk(ch + 1);
+            if (!(x.ablate & 1)) {
+                // the 9 x KS K-steps of the chunk as ONE software pipeline: fragments are read two K-steps ahead, across tap
+                // boundaries (per-tap pipelines exposed an LDS round trip at every tap: ~250 cycles per 2-MFMA K-step)
+                constexpr int S = 9 * KS;
+                half8 fa[3], f0[3], f1[3];
+                auto rd = [&](int sq, int slot) __attribute__((always_inline)) {
+                    const int t = sq / KS, ks = sq - t * KS;
+                    const int toff = (a.dy[t] * g.HW + a.dx[t]) * tstr + ks * 32;
+                    f0[slot] = *reinterpret_cast<const half8*>(tile + bbase[0] + toff);
+                    f1[slot] = *reinterpret_cast<const half8*>(tile + bbase[1] + toff);
+                    fa[slot] = *reinterpret_cast<const half8*>(wl0 + t * WBUF + abase + ks * 32);
+                };
+                rd(0, 0);
+                rd(1, 1);
+                for (int sq = 0; sq < S; sq += 3) {
+                    rd(sq + 2, 2);
+                    acc[0][0] = mma<BF>(fa[0], f0[0], acc[0][0]);
+                    acc[0][1] = mma<BF>(fa[0], f1[0], acc[0][1]);
+                    if (sq + 3 < S) rd(sq + 3, 0);
+                    acc[0][0] = mma<BF>(fa[1], f0[1], acc[0][0]);
+                    acc[0][1] = mma<BF>(fa[1], f1[1], acc[0][1]);
+                    if (sq + 4 < S) rd(sq + 4, 1);
+                    acc[0][0] = mma<BF>(fa[2], f0[2], acc[0][0]);
+                    acc[0][1] = mma<BF>(fa[2], f1[2], acc[0][1]);
+                }
+            }
+            stamp();
+            __syncthreads();
+        }
+        if (x.ablate & 16) return;
+        // ---- flat epilogue: registers -> LDS [pixel][OSTR] -> 16-byte pieces of 256 consecutive pixels ----
+        constexpr int OSTRF = MT * 64 + 16;
+        char* otf = smem;
+        float* blf = reinterpret_cast<float*>(smem + (size_t)CONV_THREADS * OSTRF);
+        if (tid < WROWS) blf[tid] = bias_r;
+        __syncthreads();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int q = wave * 64 + nt * 32 + l31;
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int ml = gq * 8 + kh * 4;
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(blf + ml);
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v[j] = acc[0][nt][gq * 4 + j] + bb[j];
+                    if (a.act) v[j] = lrelu(v[j]);
+                }
+                u32x2_t o;
+                o[0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
+                o[1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
+                *reinterpret_cast<u32x2_t*>(otf + q * OSTRF + ml * 2) = o;
+            }
+        }
+        __syncthreads();
+        stamp();
+        int m_cntf = a.M - x.m_base;
+        m_cntf = m_cntf > WROWS ? WROWS : m_cntf;
+        const int lcpp = m_cntf >= 32 ? 2 : (m_cntf >= 16 ? 1 : 0);          // pieces per pixel: 4, 2 or 1 (m_cnt = 32, 16, 8)
+        const bool has_maskf = a.mask.p != nullptr, has_addf = a.add.p != nullptr;
+        const int npieces = CONV_THREADS << lcpp;
+        half8 mk[4], ad[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * CONV_THREADS;
+            const int q = e >> lcpp, c = e & ((1 << lcpp) - 1);
+            const bool on = e < npieces && n0 + (q >> lhw) < a.N;
+            mk[u] = zero_h8(); ad[u] = zero_h8();
+            if (on && has_maskf) mk[u] = ld_h8((const h16*)a.mask.p + ((pixb + q) * a.mask.cs + a.mask.co + x.m_base + c * 8));
+            if (on && has_addf) ad[u] = ld_h8((const h16*)a.add.p + ((pixb + q) * a.add.cs + a.add.co + x.m_base + c * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = tid + u * CONV_THREADS;
+            const int q = e >> lcpp, c = e & ((1 << lcpp) - 1);
+            const bool on = e < npieces && n0 + (q >> lhw) < a.N;
+            if (!on) continue;
+            u32x4_t o = *reinterpret_cast<const u32x4_t*>(otf + q * OSTRF + c * 16);
+            if (has_addf || has_maskf) {
+                const u32x4_t ab = __builtin_bit_cast(u32x4_t, ad[u]), mb = __builtin_bit_cast(u32x4_t, mk[u]);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    float v0, v1;
+                    if constexpr (BF) {
+                        v0 = bf_lo(o[w]) + (has_addf ? bf_lo(ab[w]) : 0.f);
+                        v1 = bf_hi(o[w]) + (has_addf ? bf_hi(ab[w]) : 0.f);
+                    } else {
+                        v0 = f16_lo(o[w]) + (has_addf ? f16_lo(ab[w]) : 0.f);
+                        v1 = f16_hi(o[w]) + (has_addf ? f16_hi(ab[w]) : 0.f);
+                    }
+                    if (has_maskf) {
+                        v0 *= lrelu_grad(f16_lo(mb[w]));
+                        v1 *= lrelu_grad(f16_hi(mb[w]));
+                    }
+                    o[w] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
+                }
+            }
+            *reinterpret_cast<u32x4_t*>((h16*)a.dst.p + ((pixb + q) * a.dst.cs + a.dst.co + x.m_base + c * 8)) = o;
+        }
+        stamp();
+        flat_done = true;
+    }
+    }
+    if (flat_done) return;
     if (x.allw) {
+        stamp();
         // ---- ALLW: per channel chunk, stage tile + all nine weight slices, one barrier, 9 x KS K-steps barrier-free ----
         const int wtotal = a.ntaps * WROWS * CC8;                    // 16-byte pieces of one chunk's weight block
         for (int ch = 0; ch < nchunks; ++ch) {
@@ -325,7 +500,9 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             }
             stage_tile(ch);
             __syncthreads();
+            stamp();
             for (int t = 0; t < a.ntaps; ++t) compute(wl0 + t * WBUF, ch * a.ntaps + t);
+            stamp();
         }
         __syncthreads();
         stamp();
@@ -603,6 +780,10 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     x.nblk = nblk_y;
     static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;      // A/B aid, read once
     x.allw = (!no_allw && conv_allw(*a, g, MT, a->kc) && !conv_async(*a, a->kc)) ? 1 : 0;
+    static const bool no_flat = getenv("SSDN_CONV_NO_FLAT") != nullptr;      // A/B aid, read once
+    const int m_last = a->M - (a->Mpad - 32);                                // real channels of the last 32-channel block
+    x.flat = (x.allw && !no_flat && CONV_THREADS == 256 && KS <= 4 && g.TW == a->W && g.TH == a->H && g.TN * g.TH * g.TW == 256 &&
+              a->N % g.TN == 0 && (m_last == 32 || m_last == 16 || m_last == 8) && (!a->up0 || !((a->H | a->W) & 1))) ? 1 : 0;
     const int grid_all = nblk_y > 1 ? ((grid + 7) / 8) * 8 * nblk_y : grid;
     hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid_all), dim3(CONV_THREADS), lds, s, *a, x);
     prof_end(3 - MT, s, flops, bytes);

@@ -165,6 +165,10 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True, cu
                     # 32-channel-block layers: prefer a tiling whose whole 9-tap weight block fits next to the tile (k_conv ALLW:
                     # one barrier per channel chunk instead of one per tap)
                     allw = mt1 and len(taps) == 9 and NP * (kc * 2 + 16) + 9 * 32 * (kc * 2 + 16) <= LDS_LIMIT
+                    # ... and, for whole-image tiles, the flat variant (register prefetch of the next 48/64-channel chunk; the
+                    # 96-channel instance has no registers left for it)
+                    flat = allw and TW == W and TH == H and TN * TH * TW == 256 and N % TN == 0 and kc <= 64
+                    allw = (allw, flat)
                     halo = NP / float(TN * TH * TW)
                     # prefer: high utilisation, then 2 workgroups per CU, then large channel chunks (fewer barriers),
                     # then small halo, then wide tiles
