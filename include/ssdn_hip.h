@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSDN_ABI_VERSION 4
+#define SSDN_ABI_VERSION 5
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -133,6 +133,13 @@ typedef struct ssdn_conv_args {
                        (tap, chunk) slice is one linear, fully coalesced DMA (SSDN_OP_WPACK writes it: wfc / wdc) */
     int32_t kreal; /* real (un-padded) input channels among the Ktot slots: only used for the profiler's algorithmic flop count
                       (0: = Ktot) */
+    /* Fused Shift2d((1,0)) + nn.MaxPool2d(2) of the conv's activated 16-bit output (SSDN_OP_POOL_FWD semantics; the reference:
+     * noise_network.py:64-67): pool.p != NULL makes the epilogue ALSO write pooled[N,H/2,W/2,M] -- the max is taken over the
+     * rounded fp16 values the epilogue stores, so the result is bit-identical to SSDN_OP_POOL_FWD applied to dst.  Only the
+     * launches ssdn_conv_fuses_pool() accepts can do this (today: forward layers whose 256-pixel tile is made of whole images,
+     * i.e. 16x16 pixels and below at BASELINE sizes); any other launch with pool.p set is an error. */
+    ssdn_view pool;
+    int32_t pool_shifted;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -378,6 +385,8 @@ int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* f
 /* Which kernel serves SSDN_OP_CONV: 0 = k_conv always; 1 (default) = the persistent LDS-DMA kernel k_cdma for 3x3 layers of
  * its shape class with at least one 256-pixel tile per CU; 2 = k_cdma for every layer of its shape class (test aid). */
 int ssdn_conv_set_mode(int mode);
+/* 1 if SSDN_OP_CONV with these arguments writes the fused max-pool output (ssdn_conv_args.pool), 0 if it cannot. */
+int ssdn_conv_fuses_pool(const ssdn_conv_args* a);
 
 /* ssdn_run_ops executes a run of consecutive SSDN_OP_WGRAD ops on one lane as ONE launch (k_wgrad_multi) when every op of the
  * run is "mergeable": at most 32768 pixels (the layers at the bottom of the U), mblocks <= 1, and a tiling the merged kernel

@@ -118,7 +118,7 @@ class Interp:
         return out
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
-                ltw, lth, ltn, kc, bf16=0, kreal=0):
+                ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -137,6 +137,8 @@ class Interp:
         if mask is not None:
             out = out * _lgrad(self.view(mask, M))
         self.store(dst, M, out)
+        if pool is not None:       # fused SSDN_OP_POOL_FWD of the stored (rounded) output
+            self.store(pool, M, self._windows(self.view(dst, M), pool_shifted).max(3).values)
 
     def _windows(self, a, shifted):
         """[N,Ho,Wo,4,C] window values in scan order (row-major); the shifted variant sees a zero row on top."""

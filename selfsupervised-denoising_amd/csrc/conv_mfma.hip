@@ -469,6 +469,35 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             }
             *reinterpret_cast<u32x4_t*>((h16*)a.dst.p + ((pixb + q) * a.dst.cs + a.dst.co + x.m_base + c * 8)) = o;
         }
+        if (a.pool.p) {
+            // fused Shift2d((1,0)) + MaxPool2d(2) (SSDN_OP_POOL_FWD): 64 pooled pixels x (1 << lcpp) pieces, straight from the
+            // transposed tile (the rounded values just stored); shifted: rows {2i-1, 2i}, row -1 is a literal 0 in the max
+            const int e = tid;
+            const int pq = e >> lcpp, c = e & ((1 << lcpp) - 1);
+            const int lw2 = a.ltw - 1, lh2 = a.lth - 1;
+            const int pj = pq & ((1 << lw2) - 1), pi = (pq >> lw2) & ((1 << lh2) - 1), tn = pq >> (lw2 + lh2);
+            if (e < (64 << lcpp) && tn < g.TN) {
+                const int r0 = a.pool_shifted ? 2 * pi - 1 : 2 * pi;
+                u32x4_t best;
+                bool have = false;
+#pragma unroll
+                for (int dr = 0; dr < 2; ++dr) {
+                    const int r = r0 + dr;
+#pragma unroll
+                    for (int dc = 0; dc < 2; ++dc) {
+                        u32x4_t v = {0u, 0u, 0u, 0u};
+                        if (r >= 0) v = *reinterpret_cast<const u32x4_t*>(otf + (((tn << a.lth) + r) * g.TW + 2 * pj + dc) * OSTRF + c * 16);
+                        if (!have) { best = v; have = true; }
+                        else {
+                            const half8 m = __builtin_elementwise_max(__builtin_bit_cast(half8, best), __builtin_bit_cast(half8, v));
+                            best = __builtin_bit_cast(u32x4_t, m);
+                        }
+                    }
+                }
+                const long long pp = (((((long long)(n0 + tn)) << lh2) + pi) << lw2) + pj;
+                *reinterpret_cast<u32x4_t*>((h16*)a.pool.p + (pp * a.pool.cs + a.pool.co + x.m_base + c * 8)) = best;
+            }
+        }
         stamp();
         flat_done = true;
     }
@@ -718,7 +747,8 @@ extern "C" int ssdn_conv_set_mode(int mode) {
     g_conv_mode = mode;
     return 0;
 }
-static bool conv_use_dma(const ssdn_conv_args* a) { return g_conv_mode > 0 && conv_dma_eligible(a, g_conv_mode == 2); }
+// (a launch that must write the fused max-pool output takes k_conv's flat path)
+static bool conv_use_dma(const ssdn_conv_args* a) { return g_conv_mode > 0 && !a->pool.p && conv_dma_eligible(a, g_conv_mode == 2); }
 static bool conv_use_gemm(const ssdn_conv_args* a) { return g_conv_mode > 0 && gemm_dma_eligible(a); }
 
 static int conv_validate(const ssdn_conv_args* a) {
@@ -758,6 +788,14 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
     return (int)conv_lds(a, g, mt);
 }
 
+// FLAT: ALLW + the 256-pixel tile is made of whole images (see k_conv)
+static bool conv_flat_ok(const ssdn_conv_args* a, const ConvGeom& g, int ks, int threads) {
+    static const bool no_flat = getenv("SSDN_CONV_NO_FLAT") != nullptr;      // A/B aid, read once
+    const int m_last = a->M - (a->Mpad - 32);                                // real channels of the last 32-channel block
+    return !no_flat && threads == 256 && ks <= 4 && g.TW == a->W && g.TH == a->H && g.TN * g.TH * g.TW == 256 && a->N % g.TN == 0 &&
+           (m_last == 32 || m_last == 16 || m_last == 8) && (!a->up0 || !((a->H | a->W) & 1));
+}
+
 template <int MT, bool BF, int KS, int CONV_THREADS>
 static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
     size_t lds = conv_lds(a, g, MT);
@@ -780,10 +818,8 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     x.nblk = nblk_y;
     static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;      // A/B aid, read once
     x.allw = (!no_allw && conv_allw(*a, g, MT, a->kc) && !conv_async(*a, a->kc)) ? 1 : 0;
-    static const bool no_flat = getenv("SSDN_CONV_NO_FLAT") != nullptr;      // A/B aid, read once
-    const int m_last = a->M - (a->Mpad - 32);                                // real channels of the last 32-channel block
-    x.flat = (x.allw && !no_flat && CONV_THREADS == 256 && KS <= 4 && g.TW == a->W && g.TH == a->H && g.TN * g.TH * g.TW == 256 &&
-              a->N % g.TN == 0 && (m_last == 32 || m_last == 16 || m_last == 8) && (!a->up0 || !((a->H | a->W) & 1))) ? 1 : 0;
+    x.flat = (x.allw && conv_flat_ok(a, g, KS, CONV_THREADS)) ? 1 : 0;
+    if (a->pool.p && !x.flat) return ssdn_set_error("conv: fused max-pool requested for a launch that does not take the flat path");
     const int grid_all = nblk_y > 1 ? ((grid + 7) / 8) * 8 * nblk_y : grid;
     hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid_all), dim3(CONV_THREADS), lds, s, *a, x);
     prof_end(3 - MT, s, flops, bytes);
@@ -806,9 +842,20 @@ static int conv_launch_ks(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
 }
 
 
+bool conv_fuses_pool(const ssdn_conv_args* a) {
+    static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;
+    if (conv_validate(a) || a->bf16 || a->dst32 || !a->act || (a->H & 1) || (a->W & 1)) return false;
+    if (conv_use_gemm(a)) return false;
+    ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
+    const bool wide = a->ltw + a->lth + a->ltn > 8;
+    return conv_uses_mt1(a, g) && !no_allw && conv_allw(*a, g, 1, a->kc) && !conv_async(*a, a->kc) &&
+           conv_flat_ok(a, g, a->kc / 16, wide ? 512 : 256);
+}
+
 int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     int rc = conv_validate(a);
     if (rc) return rc;
+    if (a->pool.p && !conv_fuses_pool(a)) return ssdn_set_error("conv: fused max-pool requested for a launch that cannot fuse it (ssdn_conv_fuses_pool)");
     if (conv_use_gemm(a)) return launch_gemm_dma(a, s);
     if (conv_use_dma(a)) return launch_conv_dma(a, s);
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);

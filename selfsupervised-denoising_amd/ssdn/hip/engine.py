@@ -216,6 +216,9 @@ class DeviceNet:
             s.ltw, s.lth, s.ltn, s.kc = a["ltw"], a["lth"], a["ltn"], a["kc"]
             s.bf16 = a["bf16"]
             s.kreal = a.get("kreal", 0)
+            s.pool, s.pool_shifted = self._view(a.get("pool")), a.get("pool_shifted", 0)
+            if a.get("pool") is not None and not L.load().ssdn_conv_fuses_pool(C.byref(s)):
+                raise L.SsdnHipError("conv %s: the plan fuses the max-pool but the library cannot (planner / library rule mismatch)" % a["layer"])
             if L.load().ssdn_conv_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("conv %s/%s: %s" % (a["layer"], a["role"], L.load().ssdn_last_error().decode()))
             return op.type, s

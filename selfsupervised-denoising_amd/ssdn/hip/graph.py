@@ -180,6 +180,20 @@ def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True, cu
     return best[1]
 
 
+def conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, cus):
+    """The library's rule (csrc/conv_mfma.hip::conv_fuses_pool; the engine cross-checks with ssdn_conv_fuses_pool): the launch
+    runs k_conv's flat path -- 32-channel blocks (<= one tile per CU), all nine weight slices next to the tile in LDS, the
+    256-pixel tile made of whole images."""
+    TW, TH, TN = 1 << ltw, 1 << lth, 1 << ltn
+    padT, padB, padL, padR = _pads(taps)
+    tiles = -(-W // TW) * -(-H // TH) * -(-N // TN)
+    NP = TN * (TH + padT + padB) * (TW + padL + padR)
+    m_last = M - (Mpad - 32)
+    return (len(taps) == 9 and tiles <= cus and Mpad >= 64 and NP * (kc * 2 + 16) + 9 * 32 * (kc * 2 + 16) <= LDS_LIMIT and
+            TW == W and TH == H and TN * TH * TW == 256 and N % TN == 0 and kc <= 64 and m_last in (32, 16, 8) and
+            H % 2 == 0 and W % 2 == 0)
+
+
 def _wg_stride(row_bytes):
     """pixel stride of the weight-gradient kernel's LDS images: == 64 (mod 128) bytes (bank-conflict-free transpose reads)"""
     return ((row_bytes + 63) & ~127) + 64
@@ -274,14 +288,20 @@ class NetPlan:
         return self.T(name, "actb", (N, H, W, C))
 
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
-              bias=True, act=True, mask=None, add=None):
+              bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0):
+        """pool: view of the pooled tensor -- the conv's epilogue also writes Shift2d + MaxPool2d(2) of its output
+        (ssdn_conv_args.pool).  Returns True if the pool was fused (the caller then emits no SSDN_OP_POOL_FWD)."""
         Ktot = c0 + c1
         Mpad = ceil_to(M, 32)
         ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None, cus=self.cus)
+        fused = pool is not None and conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.cus) and \
+            not os.environ.get("SSDN_NO_POOL_FUSION")
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                    taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
                                    dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"),
-                                   kreal=(layer.cin if role == "fwd" else layer.M))))
+                                   kreal=(layer.cin if role == "fwd" else layer.M),
+                                   pool=pool if fused else None, pool_shifted=int(pool_shifted) if fused else 0)))
+        return fused
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
                m_off=0, c_off=0, with_bias=True, cblocks=None, mblocks=1):
@@ -363,26 +383,31 @@ class NetPlan:
         x16 = self.act("x16", N, H, W, 32)     # C real channels, zero padded to 32 (the first layer reads a 16-channel view)
         f.append(Op("pack_input", dict(src=self.prefix + "in32", dst=View(x16), B=B, C=C, H=H, W=W, R=self.R, cpad=32)))
 
-        def enc(name, lname, src, cin_slots, h, w):
+        fused_pool = {}
+
+        def enc(name, lname, src, cin_slots, h, w, pool_name=None):
             t = self.act(name, N, h, w, 48)
-            self._conv(f, L[lname], "fwd", View(src), cin_slots, 0, None, 0, N, h, w, t3, 48, dst=View(t))
+            pv = View(self.act(pool_name, N, h // 2, w // 2, 48)) if pool_name else None
+            fused_pool[name] = self._conv(f, L[lname], "fwd", View(src), cin_slots, 0, None, 0, N, h, w, t3, 48, dst=View(t),
+                                          pool=pv, pool_shifted=int(bs))
             return t
 
         def pool(name, src, h, w):
             t = self.act(name, N, h // 2, w // 2, 48)
-            f.append(Op("pool_fwd", dict(act=View(src), pooled=View(t), N=N, H=h, W=w, C=48, shifted=int(bs))))
+            if not fused_pool.get(src[len(self.prefix):]):        # (else: written by the producing conv's epilogue)
+                f.append(Op("pool_fwd", dict(act=View(src), pooled=View(t), N=N, H=h, W=w, C=48, shifted=int(bs))))
             return t
 
         e0 = enc("e0", "encode_block_1.0", x16, 16, H, W)
-        e1 = enc("e1", "encode_block_1.2", e0, 48, H, W)
+        e1 = enc("e1", "encode_block_1.2", e0, 48, H, W, "p1")
         p1 = pool("p1", e1, H, W)
-        e2 = enc("e2", "encode_block_2.0", p1, 48, H // 2, W // 2)
+        e2 = enc("e2", "encode_block_2.0", p1, 48, H // 2, W // 2, "p2")
         p2 = pool("p2", e2, H // 2, W // 2)
-        e3 = enc("e3", "encode_block_3.0", p2, 48, H // 4, W // 4)
+        e3 = enc("e3", "encode_block_3.0", p2, 48, H // 4, W // 4, "p3")
         p3 = pool("p3", e3, H // 4, W // 4)
-        e4 = enc("e4", "encode_block_4.0", p3, 48, H // 8, W // 8)
+        e4 = enc("e4", "encode_block_4.0", p3, 48, H // 8, W // 8, "p4")
         p4 = pool("p4", e4, H // 8, W // 8)
-        e5 = enc("e5", "encode_block_5.0", p4, 48, H // 16, W // 16)
+        e5 = enc("e5", "encode_block_5.0", p4, 48, H // 16, W // 16, "p5")
         p5 = pool("p5", e5, H // 16, W // 16)
         e6 = enc("e6", "encode_block_6.0", p5, 48, H // 32, W // 32)
 

@@ -208,8 +208,20 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
             dn.t[dst].fill_(float("nan"))
         else:
             dn.t[dst.t][..., dst.co:dst.co + ch] = float("nan")
+        pv = op.a.get("pool") if op.type == "conv" else None
+        if pv is not None:
+            dn.t[pv.t][..., pv.co:pv.co + ch] = float("nan")
         OpList([rec]).run(current_stream())
         torch.cuda.synchronize()
+        if pv is not None:
+            # fused max-pool: exactly SSDN_OP_POOL_FWD of what the launch itself stored (max is exact on the rounded values)
+            mine = dn.t[dst.t][..., dst.co:dst.co + ch].float().cpu()
+            want = it._windows(mine, op.a["pool_shifted"]).max(3).values
+            gotp = dn.t[pv.t][..., pv.co:pv.co + ch].float().cpu()
+            if not torch.equal(gotp, want):
+                failures.append("op %d conv %s: fused max-pool differs from pool(dst) in %d elements" % (
+                    i, op.a["layer"], int((gotp != want).sum())))
+            dn.t[pv.t][..., pv.co:pv.co + ch] = it.t[pv.t][..., pv.co:pv.co + ch].to(dev()).to(dn.t[pv.t].dtype)
         if kind == "f32":
             got, ref = dn.t[dst].cpu(), it.t[dst]
         else:
