@@ -140,6 +140,15 @@ typedef struct ssdn_conv_args {
      * i.e. 16x16 pixels and below at BASELINE sizes); any other launch with pool.p set is an error. */
     ssdn_view pool;
     int32_t pool_shifted;
+    /* Fused SSDN_OP_UPSUM_BWD (data-gradient role of a decoder's first conv, whose input is cat(upsample(x), skip)):
+     * upsum.p != NULL => output channels [0, upsum_c) are NOT stored to dst; their 2x2 sums (over the bf16-rounded values, in
+     * fp32, window scan order) times LeakyReLU'(upsum_mask) are stored to upsum[N,H/2,W/2,..] -- bit-identical to
+     * SSDN_OP_UPSUM_BWD applied to the tensor this launch would have stored.  Channels >= upsum_c (the skip gradient) go to
+     * dst as usual.  Needs bf16 = 1, no mask / add, even H, W; upsum_c a multiple of 8 -- and of 96 for the launches that
+     * run k_cdma.  ssdn_conv_fuses_upsum() tells whether a launch can do it; otherwise upsum.p set is an error. */
+    ssdn_view upsum;
+    ssdn_view upsum_mask;
+    int32_t upsum_c;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -387,6 +396,8 @@ int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* f
 int ssdn_conv_set_mode(int mode);
 /* 1 if SSDN_OP_CONV with these arguments writes the fused max-pool output (ssdn_conv_args.pool), 0 if it cannot. */
 int ssdn_conv_fuses_pool(const ssdn_conv_args* a);
+/* 1 if SSDN_OP_CONV with these arguments applies the fused SSDN_OP_UPSUM_BWD (ssdn_conv_args.upsum), 0 if it cannot. */
+int ssdn_conv_fuses_upsum(const ssdn_conv_args* a);
 
 /* ssdn_run_ops executes a run of consecutive SSDN_OP_WGRAD ops on one lane as ONE launch (k_wgrad_multi) when every op of the
  * run is "mergeable": at most 32768 pixels (the layers at the bottom of the U), mblocks <= 1, and a tiling the merged kernel

@@ -118,7 +118,7 @@ class Interp:
         return out
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
-                ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0):
+                ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -136,6 +136,13 @@ class Interp:
             out = out + self.view(add, M)
         if mask is not None:
             out = out * _lgrad(self.view(mask, M))
+        if upsum is not None:      # fused SSDN_OP_UPSUM_BWD of the (rounded) channels below upsum_c; the rest goes to dst
+            r = _r16(out[..., :upsum_c], self.fp16, self.plan.tensors[dst.t].kind)
+            sm = r.reshape(N, H // 2, 2, W // 2, 2, upsum_c).sum((2, 4))
+            self.store(upsum, upsum_c, sm * _lgrad(self.view(upsum_mask, upsum_c)))
+            if M > upsum_c:
+                self.alloc(dst.t)[..., dst.co + upsum_c:dst.co + M] = _r16(out[..., upsum_c:], self.fp16, self.plan.tensors[dst.t].kind)
+            return
         self.store(dst, M, out)
         if pool is not None:       # fused SSDN_OP_POOL_FWD of the stored (rounded) output
             self.store(pool, M, self._windows(self.view(dst, M), pool_shifted).max(3).values)

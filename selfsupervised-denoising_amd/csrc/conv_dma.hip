@@ -106,7 +106,9 @@ struct CdTile { int n, y0, x0; };
 
 }  // namespace
 
-// EPI: bit 0 = multiply by LeakyReLU'(mask), bit 1 = add the skip gradient (data-gradient role only)
+// EPI: bit 0 = multiply by LeakyReLU'(mask), bit 1 = add the skip gradient (data-gradient role only), bit 2 = fused
+// SSDN_OP_UPSUM_BWD: a pass of the epilogue is 2 rows x 16 pixels = 8 low-resolution pixels, whose 2x2 sums times
+// LeakyReLU'(upsum_mask) are stored instead of the 32 pixels
 template <int MT, bool BF, int EPI>
 __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -115,7 +117,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     constexpr int NWQ = MT * 3;               // 1 KiB DMA instructions per 48-channel weight slice; the 16-channel slice has MT
     constexpr int OSTR = MT * 64 + 16;        // epilogue: LDS bytes per pixel (16 B x odd: conflict-free ds_write_b128)
     constexpr int NEK = MT * 2;               // epilogue: 64-lane 16-byte row instructions per 32-pixel pass
-    constexpr bool HAS_MASK = (EPI & 1) != 0, HAS_ADD = (EPI & 2) != 0;
+    constexpr bool HAS_MASK = (EPI & 1) != 0, HAS_ADD = (EPI & 2) != 0, HAS_UPS = (EPI & 4) != 0;
+    constexpr int NUK = (8 * MT * 4 + 63) / 64;   // upsum: 64-lane instructions per pass (8 pixels x cpp pieces)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool wload = w < 2;                 // waves 0-1 fetch weights, waves 2-3 fetch tiles
@@ -300,6 +303,15 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     const float slope = a.act ? LRELU_SLOPE : 1.f;
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, HAS_MASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(a.add.p, 0, HAS_ADD ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_up = __builtin_amdgcn_make_buffer_rsrc(a.upsum.p, 0, HAS_UPS ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_um = __builtin_amdgcn_make_buffer_rsrc(a.upsum_mask.p, 0, HAS_UPS ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    int u_pc[NUK];     // upsum: low-res pixel of the pass | piece << 8, or -1
+#pragma unroll
+    for (int k = 0; k < NUK; ++k) {
+        const int p = k * 64 + lane;
+        const int j = p / cpp, c = p - j * cpp;
+        u_pc[k] = p < 8 * cpp ? (j | (c << 8)) : -1;
+    }
 
     stamp();
     for (;;) {
@@ -445,6 +457,40 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         const int piece = mt * 4 + 2 * gp + kh;
                         *reinterpret_cast<u32x4_t*>(reg + l31 * OSTR + piece * 16) = o;
                     }
+                if constexpr (HAS_UPS) {
+                    // fused UPSUM_BWD: low-res pixel j of the pass = pixels (row 0|1, column 2j|2j+1), summed in scan order
+                    const int pixl = (cur.n * (a.H >> 1) + ((cur.y0 + 4 * w + 2 * nt) >> 1)) * (a.W >> 1) + (cur.x0 >> 1);
+                    u32x4_t um[NUK];
+#pragma unroll
+                    for (int k = 0; k < NUK; ++k) {
+                        int upc = u_pc[k];
+                        asm volatile("" : "+v"(upc));
+                        const bool on = upc >= 0;
+                        const int j = upc & 255, c16 = (upc >> 8) << 4;
+                        um[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, on ? ((pixl + j) * a.upsum_mask.cs + a.upsum_mask.co + x.m_base) * 2 + c16 : (int)0x80000000, 0, 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NUK; ++k) {
+                        int upc = u_pc[k];
+                        asm volatile("" : "+v"(upc));
+                        const bool on = upc >= 0;
+                        const int j = upc & 255, c16 = (upc >> 8) << 4;
+                        float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + (on ? ((q4 >> 1) * 16 + 2 * j + (q4 & 1)) * OSTR + c16 : 0));
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) { sum[2 * q] += bf_lo(o[q]); sum[2 * q + 1] += bf_hi(o[q]); }
+                        }
+                        u32x4_t r;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const int mlo = (int)(short)(um[k][q] & 0xffffu), mhi = (int)um[k][q] >> 16;
+                            r[q] = pack_bf16x2(sum[2 * q] * (mlo > 0 ? 1.f : LRELU_SLOPE), sum[2 * q + 1] * (mhi > 0 ? 1.f : LRELU_SLOPE));
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(r, rs_up, on ? ((pixl + j) * a.upsum.cs + a.upsum.co + x.m_base) * 2 + c16 : (int)0x80000000, 0, 0);
+                    }
+                } else {
                 // LDS -> HBM: whole 16-byte pieces, pixel-contiguous
 #pragma unroll
                 for (int k = 0; k < NEK; ++k) {
@@ -475,6 +521,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         }
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+                }
                 }
             }
         }
@@ -512,6 +559,7 @@ bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size) {
     if (a->c0 % 48 && a->c0 != a->Ktot) return false;           // a chunk never straddles the two sources
     if ((a->M & 7) || (a->Mpad & 31)) return false;
     if (!a->bf16 && (a->mask.p || a->add.p)) return false;      // mask / skip gradient: data-gradient role only
+    if (a->upsum.p && (!a->bf16 || a->mask.p || a->add.p || a->upsum_c % 96 || a->upsum_c > a->M)) return false;
     // persistent grid: worth it from about one 256-pixel tile per CU upwards (smaller layers: k_conv's 32-channel blocks)
     int cus = ssdn_device_cus();
     if (cus <= 0) cus = 256;
@@ -558,6 +606,12 @@ static int cd_launch(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
 template <int MT>
 static int cd_launch_role(const ssdn_conv_args* a, const CdAux& x, hipStream_t s) {
     if (!a->bf16) return cd_launch<MT, false, 0>(a, x, s);
+    if (a->upsum.p && x.m_base < a->upsum_c) {      // block of up-sampled-input channels: fused UPSUM_BWD (MT = 3 only)
+        if constexpr (MT == 3) {
+            if (x.m_base + 96 <= a->upsum_c && x.m_cnt == 96 && !a->mask.p && !a->add.p) return cd_launch<3, true, 4>(a, x, s);
+        }
+        return ssdn_set_error("conv_dma: fused upsum needs whole 96-channel blocks without mask / add");
+    }
     const int epi = (a->mask.p ? 1 : 0) | (a->add.p ? 2 : 0);
     switch (epi) {
         case 0: return cd_launch<MT, true, 0>(a, x, s);

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
         for (int u = 0; u < 4; ++u) {
             const int e = tid + u * CONV_THREADS;
             const int q = e >> lcpp, c = e & ((1 << lcpp) - 1);
-            const bool on = e < npieces && n0 + (q >> lhw) < a.N;
+            const bool on = e < npieces && n0 + (q >> lhw) < a.N && !(a.upsum.p && x.m_base + c * 8 < a.upsum_c);
             if (!on) continue;
             u32x4_t o = *reinterpret_cast<const u32x4_t*>(otf + q * OSTRF + c * 16);
             if (has_addf || has_maskf) {
@@ -468,6 +468,32 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
                 }
             }
             *reinterpret_cast<u32x4_t*>((h16*)a.dst.p + ((pixb + q) * a.dst.cs + a.dst.co + x.m_base + c * 8)) = o;
+        }
+        if constexpr (BF) {
+        if (a.upsum.p) {
+            // fused SSDN_OP_UPSUM_BWD for the channels below upsum_c: 2x2 sums (scan order, fp32) of the bf16 values in the
+            // transposed tile, times LeakyReLU'(upsum_mask), to the half-resolution tensor
+            const int e = tid;
+            const int pq = e >> lcpp, c = e & ((1 << lcpp) - 1);
+            const int lw2 = a.ltw - 1, lh2 = a.lth - 1;
+            const int pj = pq & ((1 << lw2) - 1), pi = (pq >> lw2) & ((1 << lh2) - 1), tn = pq >> (lw2 + lh2);
+            if (e < (64 << lcpp) && tn < g.TN && x.m_base + c * 8 < a.upsum_c) {
+                const long long pp = (((((long long)(n0 + tn)) << lh2) + pi) << lw2) + pj;
+                const u32x4_t um = *reinterpret_cast<const u32x4_t*>((const h16*)a.upsum_mask.p + (pp * a.upsum_mask.cs + a.upsum_mask.co + x.m_base + c * 8));
+                float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int q4 = 0; q4 < 4; ++q4) {
+                    const u32x4_t o = *reinterpret_cast<const u32x4_t*>(otf + (((tn << a.lth) + 2 * pi + (q4 >> 1)) * g.TW + 2 * pj + (q4 & 1)) * OSTRF + c * 16);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { sum[2 * q] += bf_lo(o[q]); sum[2 * q + 1] += bf_hi(o[q]); }
+                }
+                u32x4_t r;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    r[q] = pack_bf16x2(sum[2 * q] * lrelu_grad(f16_lo(um[q])), sum[2 * q + 1] * lrelu_grad(f16_hi(um[q])));
+                *reinterpret_cast<u32x4_t*>((h16*)a.upsum.p + (pp * a.upsum.cs + a.upsum.co + x.m_base + c * 8)) = r;
+            }
+        }
         }
         if (a.pool.p) {
             // fused Shift2d((1,0)) + MaxPool2d(2) (SSDN_OP_POOL_FWD): 64 pooled pixels x (1 << lcpp) pieces, straight from the
@@ -820,6 +846,7 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     x.allw = (!no_allw && conv_allw(*a, g, MT, a->kc) && !conv_async(*a, a->kc)) ? 1 : 0;
     x.flat = (x.allw && conv_flat_ok(a, g, KS, CONV_THREADS)) ? 1 : 0;
     if (a->pool.p && !x.flat) return ssdn_set_error("conv: fused max-pool requested for a launch that does not take the flat path");
+    if (a->upsum.p && !x.flat) return ssdn_set_error("conv: fused upsum requested for a launch that does not take the flat path");
     const int grid_all = nblk_y > 1 ? ((grid + 7) / 8) * 8 * nblk_y : grid;
     hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid_all), dim3(CONV_THREADS), lds, s, *a, x);
     prof_end(3 - MT, s, flops, bytes);
@@ -852,9 +879,25 @@ bool conv_fuses_pool(const ssdn_conv_args* a) {
            conv_flat_ok(a, g, a->kc / 16, wide ? 512 : 256);
 }
 
+static bool conv_flat_path(const ssdn_conv_args* a) {
+    static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;
+    ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
+    const bool wide = a->ltw + a->lth + a->ltn > 8;
+    return conv_uses_mt1(a, g) && !no_allw && conv_allw(*a, g, 1, a->kc) && !conv_async(*a, a->kc) &&
+           conv_flat_ok(a, g, a->kc / 16, wide ? 512 : 256);
+}
+bool conv_fuses_upsum(const ssdn_conv_args* a) {
+    if (conv_validate(a) || !a->bf16 || a->dst32 || a->mask.p || a->add.p || (a->H & 1) || (a->W & 1)) return false;
+    if ((a->upsum_c & 7) || a->upsum_c > a->M || a->upsum_c <= 0) return false;
+    if (conv_use_gemm(a)) return false;
+    if (conv_use_dma(a)) return a->upsum_c % 96 == 0;
+    return conv_flat_path(a);
+}
+
 int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     int rc = conv_validate(a);
     if (rc) return rc;
+    if (a->upsum.p && !conv_fuses_upsum(a)) return ssdn_set_error("conv: fused upsum requested for a launch that cannot fuse it (ssdn_conv_fuses_upsum)");
     if (a->pool.p && !conv_fuses_pool(a)) return ssdn_set_error("conv: fused max-pool requested for a launch that cannot fuse it (ssdn_conv_fuses_pool)");
     if (conv_use_gemm(a)) return launch_gemm_dma(a, s);
     if (conv_use_dma(a)) return launch_conv_dma(a, s);

@@ -250,16 +250,19 @@ class NetPlan:
     prefix   unique tensor-name prefix (a Denoiser owns up to two nets)
     B,H,W    input batch / spatial size (H == W when blindspot)
     cus      compute units of the device (sizes the persistent wgrad grids)
+    dev_cus  compute units the LIBRARY sees (ssdn_device_cus: its kernel-selection rules use it); only differs from `cus`
+             when a test plans small persistent grids on a big device
     """
 
     def __init__(self, prefix: str, in_channels: int, out_channels: int, blindspot: bool, B: int, H: int, W: int,
-                 cus: int = 256, train: bool = True, param_base: int = 0):
+                 cus: int = 256, train: bool = True, param_base: int = 0, dev_cus: Optional[int] = None):
         if H % 32 or W % 32:
             raise ValueError("input height/width must be multiples of 32 (NoiseNetwork.input_wh_mul)")
         if blindspot and H != W:
             raise ValueError("blind-spot mode needs square inputs")
         self.prefix, self.C, self.Cout, self.blindspot = prefix, in_channels, out_channels, blindspot
         self.B, self.H, self.W, self.cus, self.train = B, H, W, cus, train
+        self.dev_cus = cus if dev_cus is None else dev_cus
         self.R = 4 if blindspot else 1
         self.N = self.R * B
         self.layers = net_layers(in_channels, out_channels, blindspot)
@@ -288,19 +291,29 @@ class NetPlan:
         return self.T(name, "actb", (N, H, W, C))
 
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
-              bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0):
+              bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0):
         """pool: view of the pooled tensor -- the conv's epilogue also writes Shift2d + MaxPool2d(2) of its output
         (ssdn_conv_args.pool).  Returns True if the pool was fused (the caller then emits no SSDN_OP_POOL_FWD)."""
         Ktot = c0 + c1
         Mpad = ceil_to(M, 32)
         ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None, cus=self.cus)
-        fused = pool is not None and conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.cus) and \
+        fused = pool is not None and conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus) and \
             not os.environ.get("SSDN_NO_POOL_FUSION")
+        if upsum is not None:
+            # fused SSDN_OP_UPSUM_BWD: k_cdma (>= one 16x16 tile per CU, whole 96-channel blocks) or k_conv's flat path
+            dma = (len(taps) == 9 and H % 16 == 0 and W % 16 == 0 and N * (H // 16) * (W // 16) >= self.dev_cus and
+                   Ktot % 48 in (0, 16) and upsum_c % 96 == 0)
+            fused = (dma or conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus)) and upsum_c % 8 == 0 and \
+                mask is None and add is None and not os.environ.get("SSDN_NO_UPSUM_FUSION")
+            if not fused:
+                upsum = upsum_mask = None
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                    taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
                                    dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"),
                                    kreal=(layer.cin if role == "fwd" else layer.M),
-                                   pool=pool if fused else None, pool_shifted=int(pool_shifted) if fused else 0)))
+                                   pool=pool if (fused and pool is not None) else None,
+                                   pool_shifted=int(pool_shifted) if (fused and pool is not None) else 0,
+                                   upsum=upsum, upsum_mask=upsum_mask, upsum_c=int(upsum_c) if upsum is not None else 0)))
         return fused
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
@@ -472,9 +485,9 @@ class NetPlan:
         gz = self.grad("gz", B, H, W, 16)
         b.append(Op("grad_pack", dict(g=self.prefix + "g32", dst=View(gz), N=B, C=self.Cout, H=H, W=W, cpad=16)))
 
-        def dgrad(layer, src, csrc, n, h, w, taps, M, dst, mask=None, add=None):
-            self._conv(b, L[layer], "dgrad", View(src), csrc, 0, None, 0, n, h, w, taps, M, dst=dst, bias=False, act=False,
-                       mask=mask, add=add)
+        def dgrad(layer, src, csrc, n, h, w, taps, M, dst, mask=None, add=None, **kw):
+            return self._conv(b, L[layer], "dgrad", View(src), csrc, 0, None, 0, n, h, w, taps, M, dst=dst, bias=False, act=False,
+                              mask=mask, add=add, **kw)
 
         # output_block.4 : 96 -> Cout
         lo4 = L["output_block.4"]
@@ -508,9 +521,10 @@ class NetPlan:
             self._wgrad(L[la], View(g_ta), 96, None, 0, 0, View(skip), c_skip, c_skip_real, N, h, w, t3, c_off=c_up, with_bias=False)
             Mx = c_up + (c_skip if need_skip_grad else 0)
             dxs = self.grad("dxs_" + tag, N, h, w, Mx)
-            dgrad(la, g_ta, 96, N, h, w, rt3, Mx, View(dxs))
             g_up = self.grad("g_up_" + tag, N, h // 2, w // 2, c_up)
-            b.append(Op("upsum_bwd", dict(src=View(dxs), mask=View(up_src), dst=View(g_up), N=N, H=h // 2, W=w // 2, C=c_up)))
+            # (the 2x2 sum + LeakyReLU' of the up-sampled half is fused into the data-gradient conv where the library can)
+            if not dgrad(la, g_ta, 96, N, h, w, rt3, Mx, View(dxs), upsum=View(g_up), upsum_mask=View(up_src), upsum_c=c_up):
+                b.append(Op("upsum_bwd", dict(src=View(dxs), mask=View(up_src), dst=View(g_up), N=N, H=h // 2, W=w // 2, C=c_up)))
             return g_up, (View(dxs, c_up) if need_skip_grad else None)
 
         g_d2b, _ = dec_bwd("decode_block_1.0", "decode_block_1.2", d1a, d1b, g_d1b, d2b, 96, x16, 32, C, H, W, "d1", need_skip_grad=False)

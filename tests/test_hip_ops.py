@@ -144,7 +144,7 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
     L.check(L.load().ssdn_conv_set_mode(conv_mode))
     cus = cus_plan or L.load().ssdn_device_cus()
     p = R.make_params(cin, cout, bs, seed=7)
-    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=cus)
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=cus, dev_cus=L.load().ssdn_device_cus())
     flat = flat_params(plan, p)
     it = Interp(plan, flat, fp16=True)
     it.t["m/in32"] = R.hash_tensor((B, cin, P, P), 91, 0, 1)
@@ -208,6 +208,9 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
             dn.t[dst].fill_(float("nan"))
         else:
             dn.t[dst.t][..., dst.co:dst.co + ch] = float("nan")
+        uv = op.a.get("upsum") if op.type == "conv" else None
+        if uv is not None:
+            dn.t[uv.t][..., uv.co:uv.co + op.a["upsum_c"]] = float("nan")
         pv = op.a.get("pool") if op.type == "conv" else None
         if pv is not None:
             dn.t[pv.t][..., pv.co:pv.co + ch] = float("nan")
@@ -222,10 +225,27 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
                 failures.append("op %d conv %s: fused max-pool differs from pool(dst) in %d elements" % (
                     i, op.a["layer"], int((gotp != want).sum())))
             dn.t[pv.t][..., pv.co:pv.co + ch] = it.t[pv.t][..., pv.co:pv.co + ch].to(dev()).to(dn.t[pv.t].dtype)
+        c_lo = 0
+        if uv is not None:
+            # fused UPSUM_BWD: the up-sampled-input channels only exist as 2x2 sums at half resolution (bf16); the rest in dst
+            uc = op.a["upsum_c"]
+            gotu, refu = dn.t[uv.t][..., uv.co:uv.co + uc].float().cpu(), it.t[uv.t][..., uv.co:uv.co + uc]
+            # each of the 4 bf16 addends may differ by one ulp (2^-8 of ITS size, not of the possibly cancelling sum's) + the
+            # sum's own rounding
+            tolu = 1.6e-2 * refu.abs() + 2e-2 * float(refu.abs().mean()) + 1e-9
+            badu = ~((gotu - refu).abs() <= tolu)
+            if badu.any():
+                failures.append("op %d conv %s: fused upsum: %d/%d elements off, max err %.3e" % (
+                    i, op.a["layer"], int(badu.sum()), badu.numel(), float(torch.nan_to_num((gotu - refu).abs(), nan=9e9).max())))
+            dn.t[uv.t][..., uv.co:uv.co + uc] = refu.to(dev()).to(dn.t[uv.t].dtype)
+            c_lo = uc
+            if c_lo >= ch:
+                i += 1
+                continue
         if kind == "f32":
             got, ref = dn.t[dst].cpu(), it.t[dst]
         else:
-            got, ref = dn.t[dst.t][..., dst.co:dst.co + ch].float().cpu(), it.t[dst.t][..., dst.co:dst.co + ch]
+            got, ref = dn.t[dst.t][..., dst.co + c_lo:dst.co + ch].float().cpu(), it.t[dst.t][..., dst.co + c_lo:dst.co + ch]
         # one ulp of the storage type (fp16: 2^-10, bf16 gradients: 2^-7 relative) + accumulation-order noise
         ulp = 1.6e-2 if (kind == "act" and plan.tensors[dst.t].kind == "actb") else 2e-3
         tol = ulp * ref.abs() + ulp * float(ref.abs().max()) * 1e-2 + 1e-9
@@ -245,7 +265,7 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
         if kind == "f32":
             dn.t[dst].copy_(ref)
         else:
-            dn.t[dst.t][..., dst.co:dst.co + ch] = ref.to(dev()).to(dn.t[dst.t].dtype)
+            dn.t[dst.t][..., dst.co + c_lo:dst.co + ch] = ref.to(dev()).to(dn.t[dst.t].dtype)
         i += 1
     os.makedirs(OUTDIR, exist_ok=True)
     with open(os.path.join(OUTDIR, "teacher_forced_%d_%d_%d_%d_%d_cus%d_mode%d.txt" % (cin, cout, int(bs), B, P, cus_plan, conv_mode)), "w") as f:
