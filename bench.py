@@ -9,9 +9,10 @@ patches, batch 32 PER GPU (weak scaling), blind-spot U-Net + posterior head + SS
 batches are resident in HBM when the timed region starts.  One "step" = one optimisation step on one minibatch.
 
 Prints ONE JSON line (rank 0) with `value` = whole-job patches/s, plus
-  roofline:     the dominant kernel (k_conv<3>, every 96-output-channel 3x3/1x1 convolution in forward and data-gradient
-                role), timed with HIP events on the launch stream inside the timed region (ssdn_profile_*), against the
-                dense fp16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md;
+  roofline:     the dominant kernel (k_cdma<3,*>: the 96-output-channel 3x3 convolutions at 32x32 and 64x64 pixels, forward
+                and data-gradient role), timed with HIP events on the launch stream inside the timed region
+                (ssdn_profile_*), against the dense fp16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md;
+  families:     the other MFMA kernel families the same way, after the timed region (k_conv by block size, k_gdma, k_wgrad);
   cpu_baseline: the CPU oracle (oracle/restate.py, torch-CPU fp32, the operator family the reference runs on) timed on
                 this box's host cores on a bounded sample of the same workload (N=1, rank 0 only).
 """
@@ -158,11 +159,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # roofline leg: HIP events around the 96-output-channel convolution launches (13 3x3 + 1x1 launches per step), on the launch
+    # roofline leg: HIP events around the launches of the dominant kernel, k_cdma<3,*> (the 96-output-channel 3x3 layers at
+    # 32x32 and 64x64 pixels, forward and data-gradient roles: 8 launches per step, 60 % of the step's flops), on the launch
     # stream, during the timed steps.  An event pair costs ~10 us of stream time (it serialises what would be back-to-back
-    # kernels), so only every 7th launch is bracketed -> the sample rotates over all layers.
-    prof_kind = L.PROF["conv_mt3"]
-    PROF_STRIDE = 7
+    # kernels), so only every 5th launch is bracketed -> the sample rotates over all eight layers.
+    prof_kind = L.PROF["cdma_mt3"]
+    PROF_STRIDE = 5
     lib.ssdn_profile_enable(prof_kind, 64 * args.steps // PROF_STRIDE + 64)
     lib.ssdn_profile_set_stride(prof_kind, PROF_STRIDE)
     barrier()
@@ -197,7 +199,7 @@ def main():
             families[name] = {"sampled_launches": int(c2.value), "avg_launch_us": round(1e3 * m2.value / c2.value, 2),
                               "tflops_algorithmic": round(f2.value / 1e12 / (m2.value / 1e3), 1) if m2.value > 0 else None,
                               "launches_per_step": round(c2.value * FAM_STRIDE / FAM_STEPS, 1),
-                              "ms_per_step_isolated_sum": round(m2.value * FAM_STRIDE / FAM_STEPS, 4)}
+                              "ms_per_step_bracketed_sum": round(m2.value * FAM_STRIDE / FAM_STEPS, 4)}
     # (b) the same loop with the minibatch arriving from (pinned) host memory every step: the PCIe-inclusive rate of
     # SURVEY.md section 8(d); reported next to `value`, never as `value`
     h2d_value = None
@@ -221,12 +223,12 @@ def main():
         # HBM-side traffic of the same kernel family: PMC passes cannot run inside this process, so the per-launch figure is
         # the committed result of tools/pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE); null if absent
         traffic, traffic_src = None, None
-        for cand in ("r02_traffic.json", "r01_final_traffic.json"):      # newest committed PMC summary
+        for cand in ("r02_traffic.json",):      # the committed PMC summary of THIS kernel (tools/pmc_traffic.sh)
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     tj = json.load(f)
                 traffic = int(tj["hbm_bytes_per_launch"])
-                traffic_src = "profiles/%s (collected at %s)" % (cand, tj.get("collected_at", "round 1, commit f0c2be4, k_conv<3>"))
+                traffic_src = "profiles/%s (collected at %s)" % (cand, tj.get("collected_at", "?"))
                 break
             except (OSError, KeyError, ValueError):
                 continue
@@ -238,7 +240,7 @@ def main():
             "config": {"workload": "ssdn gauss25 sigma_known, %dx%d RGB patches, batch %d per GPU, blind-spot U-Net fwd+bwd + posterior head + Adam" % (P, P, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "achieved_train_tflops_algorithmic": round(value * TRAIN_GFLOP_PER_PATCH / 1e3, 2)},
-            "roofline": {"bound": "mfma", "kernel": "96-output-channel convolutions, fwd + dgrad roles: k_cdma<3,*> (persistent LDS-DMA 3x3, the full-resolution layers) + k_conv<3,*> (1x1 head, small layers); flops counted on REAL channels",
+            "roofline": {"bound": "mfma", "kernel": "k_cdma<3,*>: persistent LDS-DMA 3x3 convolution on 96-output-channel blocks (decode_block_1.*/2.*, forward + data-gradient roles, 8 launches per step); flops counted on REAL channels",
                          "achieved": round(achieved, 2), "peak": MFMA_FP16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                          "traffic_unit": "HBM-side bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE from separate --pmc passes over this "

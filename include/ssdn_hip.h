@@ -149,6 +149,14 @@ typedef struct ssdn_conv_args {
     ssdn_view upsum;
     ssdn_view upsum_mask;
     int32_t upsum_c;
+    /* Fused SSDN_OP_UNROT_BWD (data gradient of the first 1x1 head layer of a blind-spot network, whose input is the
+     * un-rotated stack of the four rotated feature maps): unrot.p != NULL => nothing is stored to dst; output channel block r
+     * (of M / 4 channels) of pixel (b, i, j) goes to unrot[(r * N + b), u - 1, v, :] times LeakyReLU'(unrot_mask there), with
+     * (u, v) the rotated coordinates of SSDN_OP_UNROT_FWD; the pixels with u == 0 (cut off by the shift) write the zero row
+     * y = H - 1 instead -- the complete tensor SSDN_OP_UNROT_BWD would have produced, bit-identical.  N of the conv = batch;
+     * needs bf16 = 1, a 1x1 layer with M = 384, H == W a power of two, no mask / add (ssdn_conv_fuses_unrot()). */
+    ssdn_view unrot;
+    ssdn_view unrot_mask;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -386,7 +394,10 @@ int ssdn_device_cus(void);
 #define SSDN_PROF_CONV_MT2 1
 #define SSDN_PROF_CONV_MT1 2
 #define SSDN_PROF_WGRAD 3
-#define SSDN_PROF_KINDS 4
+#define SSDN_PROF_GEMM 4      /* k_gdma: 1x1 layers as one-pass LDS-DMA GEMMs */
+#define SSDN_PROF_CDMA_MT3 5  /* k_cdma<3,*>: the persistent LDS-DMA 3x3 kernel on 96-channel blocks (the dominant kernel) */
+#define SSDN_PROF_CDMA_MT21 6 /* k_cdma<2,*>, k_cdma<1,*> */
+#define SSDN_PROF_KINDS 7
 int ssdn_profile_enable(int kind, int max_launches);
 int ssdn_profile_set_stride(int kind, int stride);
 int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* flops, double* bytes);
@@ -398,6 +409,8 @@ int ssdn_conv_set_mode(int mode);
 int ssdn_conv_fuses_pool(const ssdn_conv_args* a);
 /* 1 if SSDN_OP_CONV with these arguments applies the fused SSDN_OP_UPSUM_BWD (ssdn_conv_args.upsum), 0 if it cannot. */
 int ssdn_conv_fuses_upsum(const ssdn_conv_args* a);
+/* 1 if SSDN_OP_CONV with these arguments applies the fused SSDN_OP_UNROT_BWD (ssdn_conv_args.unrot), 0 if it cannot. */
+int ssdn_conv_fuses_unrot(const ssdn_conv_args* a);
 
 /* ssdn_run_ops executes a run of consecutive SSDN_OP_WGRAD ops on one lane as ONE launch (k_wgrad_multi) when every op of the
  * run is "mergeable": at most 32768 pixels (the layers at the bottom of the U), mblocks <= 1, and a tiling the merged kernel

@@ -118,7 +118,8 @@ class Interp:
         return out
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
-                ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0):
+                ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
+                unrot=None, unrot_mask=None):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -136,6 +137,15 @@ class Interp:
             out = out + self.view(add, M)
         if mask is not None:
             out = out * _lgrad(self.view(mask, M))
+        if unrot is not None:      # fused SSDN_OP_UNROT_BWD of the (rounded) output; nothing goes to dst
+            C4 = M // 4
+            g = _r16(out, self.fp16, self.plan.tensors[unrot.t].kind)
+            outs = []
+            for r, ang in enumerate((0, 90, 180, 270)):
+                gs = self._rot(g[..., r * C4:(r + 1) * C4], ang)
+                outs.append(torch.cat([gs[:, 1:], torch.zeros(N, 1, W, C4)], 1))
+            self.store(unrot, C4, torch.cat(outs, 0) * _lgrad(self.view(unrot_mask, C4)))
+            return
         if upsum is not None:      # fused SSDN_OP_UPSUM_BWD of the (rounded) channels below upsum_c; the rest goes to dst
             r = _r16(out[..., :upsum_c], self.fp16, self.plan.tensors[dst.t].kind)
             sm = r.reshape(N, H // 2, 2, W // 2, 2, upsum_c).sum((2, 4))

@@ -886,6 +886,12 @@ static bool conv_flat_path(const ssdn_conv_args* a) {
     return conv_uses_mt1(a, g) && !no_allw && conv_allw(*a, g, 1, a->kc) && !conv_async(*a, a->kc) &&
            conv_flat_ok(a, g, a->kc / 16, wide ? 512 : 256);
 }
+bool conv_fuses_unrot(const ssdn_conv_args* a) {
+    // (the query is about the launch WITH the fused output requested)
+    ssdn_conv_args q = *a;
+    if (!q.unrot.p) { q.unrot = q.dst; q.unrot_mask = q.dst; }
+    return !conv_validate(&q) && conv_use_gemm(&q);
+}
 bool conv_fuses_upsum(const ssdn_conv_args* a) {
     if (conv_validate(a) || !a->bf16 || a->dst32 || a->mask.p || a->add.p || (a->H & 1) || (a->W & 1)) return false;
     if ((a->upsum_c & 7) || a->upsum_c > a->M || a->upsum_c <= 0) return false;
@@ -897,6 +903,7 @@ bool conv_fuses_upsum(const ssdn_conv_args* a) {
 int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     int rc = conv_validate(a);
     if (rc) return rc;
+    if (a->unrot.p && !conv_fuses_unrot(a)) return ssdn_set_error("conv: fused UNROT_BWD requested for a launch that cannot fuse it (ssdn_conv_fuses_unrot)");
     if (a->upsum.p && !conv_fuses_upsum(a)) return ssdn_set_error("conv: fused upsum requested for a launch that cannot fuse it (ssdn_conv_fuses_upsum)");
     if (a->pool.p && !conv_fuses_pool(a)) return ssdn_set_error("conv: fused max-pool requested for a launch that cannot fuse it (ssdn_conv_fuses_pool)");
     if (conv_use_gemm(a)) return launch_gemm_dma(a, s);

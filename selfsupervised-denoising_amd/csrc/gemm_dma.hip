@@ -21,6 +21,7 @@ namespace {
 struct GdAux {
     int nch;      // Ktot / 32
     int ntiles;   // pixel tiles of TP
+    int lp;       // fused UNROT_BWD: log2 of the image side
 };
 
 __device__ __forceinline__ void gd_dma16(unsigned lds_addr, int voff, u32x4_t rs, int soff) {
@@ -49,7 +50,8 @@ __device__ __forceinline__ void gd_wait_groups(int n) {
 
 }  // namespace
 
-// wave grid NWP (pixels) x NWM (channels); a wave owns WP x 32 pixels and WM x 32 output channels.  EPI bit 0: LeakyReLU' mask
+// wave grid NWP (pixels) x NWM (channels); a wave owns WP x 32 pixels and WM x 32 output channels.  EPI bit 0: LeakyReLU' mask;
+// bit 1: fused SSDN_OP_UNROT_BWD (the 96-channel block r of a pixel goes, times LeakyReLU', to its place in rotation r's tensor)
 template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
 __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, GdAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     constexpr int NIA = TP / 16, NIB = TM / 16, PA = (NIA + NLA - 1) / NLA, PB = (NIB + NLB - 1) / NLB;
     constexpr int BOFF = DA * ABYTES, BIAS_OFF = BOFF + DB * BBYTES, DUMMY_OFF = BIAS_OFF + TM * 4;
     constexpr int OSTR = WM * 64 + 16, NEK = WM * 2, CPP = WM * 4;
-    constexpr bool HAS_MASK = (EPI & 1) != 0;
+    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / NWM, wm = w - wp * NWM;
@@ -74,6 +76,8 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     const u32x4_t rs_w = {(unsigned)wgp, (unsigned)(wgp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_um = __builtin_amdgcn_make_buffer_rsrc(a.unrot_mask.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
 
     // DMA lane constants: lane -> (row lane >> 2 of a 16-row instruction, LDS piece lane & 3); the piece fetched is the swizzled one
     const int drow = lane >> 2, dpiece = (lane & 3) ^ ((drow >> 2) & 3);
@@ -203,19 +207,38 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
         for (int k0 = 0; k0 < NEK; k0 += 6) {
             u32x4_t mb[6];
             int goff[6], loff[6];
+            bool live[6];
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 const int p = (k0 + k) * 64 + lane;
                 const int px = p / CPP, c16 = (p - px * CPP) << 4;
                 const int pix = pix_p + px;
                 loff[k] = px * OSTR + c16;
-                goff[k] = (pix * a.dst.cs + a.dst.co + wm * WM * 32) * 2 + c16;
-                if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + wm * WM * 32) * 2 + c16, 0, 0);
+                live[k] = true;
+                if constexpr (UNROT) {
+                    // (b, i, j) of the pixel (H == W == P, a power of two), rotation r of the piece's 96-channel block
+                    const int lp = x.lp, P = 1 << lp;
+                    const int j = pix & (P - 1), i = (pix >> lp) & (P - 1), b = pix >> (2 * lp);
+                    const int ch = wm * WM * 32 + (c16 >> 1);
+                    const int r = ch >= 288 ? 3 : (ch >= 192 ? 2 : (ch >= 96 ? 1 : 0)), cc = ch - r * 96;
+                    const int u = r == 0 ? i : (r == 1 ? P - 1 - j : (r == 2 ? P - 1 - i : j));
+                    const int v = r == 0 ? j : (r == 1 ? i : (r == 2 ? P - 1 - j : P - 1 - i));
+                    live[k] = u >= 1;                                  // u == 0: the shift cut it off -> zero row y = P-1
+                    const int dpix = (((((r * a.N + b) << lp) + (u >= 1 ? u - 1 : P - 1))) << lp) + v;
+                    goff[k] = (dpix * a.unrot.cs + a.unrot.co + cc) * 2;
+                    mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
+                } else {
+                    goff[k] = (pix * a.dst.cs + a.dst.co + wm * WM * 32) * 2 + c16;
+                    if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + wm * WM * 32) * 2 + c16, 0, 0);
+                }
             }
 #pragma unroll
             for (int k = 0; k < 6; ++k) {
                 u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + loff[k]);
-                if constexpr (HAS_MASK) {
+                if constexpr (UNROT) {
+                    if (!live[k]) o = u32x4_t{0u, 0u, 0u, 0u};
+                }
+                if constexpr (HAS_MASK || UNROT) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float v0, v1;
@@ -227,7 +250,8 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                         o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
                     }
                 }
-                __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+                if constexpr (UNROT) __builtin_amdgcn_raw_buffer_store_b128(o, rs_ur, goff[k], 0, 0);
+                else __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
             }
         }
     }
@@ -236,6 +260,9 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
 // ---- host ----------------------------------------------------------------------------------------------------------------------
 bool gemm_dma_eligible(const ssdn_conv_args* a) {
     if (a->ntaps != 1 || a->dy[0] || a->dx[0] || a->up0 || a->c1 || a->src1.p || a->dst32 || a->add.p) return false;
+    if (a->pool.p || a->upsum.p) return false;
+    if (a->unrot.p && (!a->bf16 || a->mask.p || a->Mpad != 384 || a->H != a->W || (a->H & (a->H - 1)) ||
+                       (long long)4 * a->N * a->H * a->W * a->unrot.cs * 2 >= (1ll << 31))) return false;
     if (a->c0 != a->Ktot || a->Ktot % 32) return false;
     if (a->M != a->Mpad || (a->Mpad != 384 && a->Mpad != 96)) return false;
     const long long px = (long long)a->N * a->H * a->W;
@@ -264,18 +291,21 @@ static int gd_launch(const ssdn_conv_args* a, hipStream_t s) {
     }
     GdAux x;
     x.nch = a->Ktot / 32;
+    x.lp = 0;
+    while ((1 << x.lp) < a->H) ++x.lp;
     const double px = (double)a->N * a->H * a->W;
     x.ntiles = (int)(px / TP);
     const int kreal = a->kreal > 0 ? a->kreal : a->Ktot;
-    prof_begin(0, s);
+    prof_begin(SSDN_PROF_GEMM, s);
     hipLaunchKernelGGL((k_gdma<WP, WM, NWP, NWM, BF, EPI>), dim3(x.ntiles), dim3(64 * NWP * NWM), LDS, s, *a, x);
-    prof_end(0, s, 2.0 * px * a->M * kreal, px * (a->c0 + a->M) * 2.0);
+    prof_end(SSDN_PROF_GEMM, s, 2.0 * px * a->M * kreal, px * (a->c0 + a->M) * 2.0);
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;
 }
 
 int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s) {
     const int epi = a->mask.p ? 1 : 0;
+    if (a->unrot.p) return gd_launch<2, 6, 4, 2, true, 2>(a, s);
     if (a->Mpad == 384) {
         if (!a->bf16) return gd_launch<2, 6, 4, 2, false, 0>(a, s);
         return epi ? gd_launch<2, 6, 4, 2, true, 1>(a, s) : gd_launch<2, 6, 4, 2, true, 0>(a, s);

@@ -222,6 +222,9 @@ class DeviceNet:
             s.upsum, s.upsum_mask, s.upsum_c = self._view(a.get("upsum")), self._view(a.get("upsum_mask")), a.get("upsum_c", 0)
             if a.get("upsum") is not None and not L.load().ssdn_conv_fuses_upsum(C.byref(s)):
                 raise L.SsdnHipError("conv %s: the plan fuses UPSUM_BWD but the library cannot (planner / library rule mismatch)" % a["layer"])
+            s.unrot, s.unrot_mask = self._view(a.get("unrot")), self._view(a.get("unrot_mask"))
+            if a.get("unrot") is not None and not L.load().ssdn_conv_fuses_unrot(C.byref(s)):
+                raise L.SsdnHipError("conv %s: the plan fuses UNROT_BWD but the library cannot (planner / library rule mismatch)" % a["layer"])
             if L.load().ssdn_conv_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("conv %s/%s: %s" % (a["layer"], a["role"], L.load().ssdn_last_error().decode()))
             return op.type, s

@@ -291,7 +291,8 @@ class NetPlan:
         return self.T(name, "actb", (N, H, W, C))
 
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
-              bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0):
+              bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
+              unrot=None, unrot_mask=None):
         """pool: view of the pooled tensor -- the conv's epilogue also writes Shift2d + MaxPool2d(2) of its output
         (ssdn_conv_args.pool).  Returns True if the pool was fused (the caller then emits no SSDN_OP_POOL_FWD)."""
         Ktot = c0 + c1
@@ -313,7 +314,8 @@ class NetPlan:
                                    kreal=(layer.cin if role == "fwd" else layer.M),
                                    pool=pool if (fused and pool is not None) else None,
                                    pool_shifted=int(pool_shifted) if (fused and pool is not None) else 0,
-                                   upsum=upsum, upsum_mask=upsum_mask, upsum_c=int(upsum_c) if upsum is not None else 0)))
+                                   upsum=upsum, upsum_mask=upsum_mask, upsum_c=int(upsum_c) if upsum is not None else 0,
+                                   unrot=unrot, unrot_mask=unrot_mask)))
         return fused
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
@@ -504,7 +506,11 @@ class NetPlan:
         lo0 = L["output_block.0"]
         self._wgrad(lo0, View(g_na), 96, View(head_in), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, cblocks=blocks, mblocks=nin // 96)
         g_d1b = self.grad("g_d1b", N, H, W, 96)
-        if bs:
+        if bs and H == W and H & (H - 1) == 0 and (B * H * W) % 256 == 0 and not os.environ.get("SSDN_NO_UNROT_FUSION"):
+            # the data-gradient GEMM scatters its four 96-channel blocks straight into the rotated tensors (fused
+            # SSDN_OP_UNROT_BWD, k_gdma; the library's rule: csrc/gemm_dma.hip::gemm_dma_eligible)
+            dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, None, unrot=View(g_d1b), unrot_mask=View(d1b))
+        elif bs:
             g_u = self.grad("g_u", B, H, W, 384)
             dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, View(g_u))
             b.append(Op("unrot_bwd", dict(src=View(g_u), dst=View(g_d1b), mask=View(d1b), B=B, P=H, C=96)))

@@ -37,7 +37,8 @@ class ConvArgs(C.Structure):
                 ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("w", vp), ("M", i32), ("Mpad", i32),
                 ("Ktot", i32), ("bias", vp), ("act", i32), ("mask", View), ("add", View), ("dst", View), ("dst32", vp),
                 ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32), ("bf16", i32), ("wc", vp), ("kreal", i32),
-                ("pool", View), ("pool_shifted", i32), ("upsum", View), ("upsum_mask", View), ("upsum_c", i32)]
+                ("pool", View), ("pool_shifted", i32), ("upsum", View), ("upsum_mask", View), ("upsum_c", i32),
+                ("unrot", View), ("unrot_mask", View)]
 
 
 class PoolArgs(C.Structure):
@@ -124,8 +125,8 @@ ABI_VERSION = 5      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirro
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
-           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum"]
-PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3)
+           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot"]
+PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6)
 
 _lib = None
 
@@ -164,6 +165,8 @@ def load() -> C.CDLL:
     lib.ssdn_profile_read.restype = C.c_int
     lib.ssdn_conv_set_mode.argtypes = [C.c_int]
     lib.ssdn_conv_set_mode.restype = C.c_int
+    lib.ssdn_conv_fuses_unrot.argtypes = [C.c_void_p]
+    lib.ssdn_conv_fuses_unrot.restype = C.c_int
     lib.ssdn_conv_fuses_upsum.argtypes = [C.c_void_p]
     lib.ssdn_conv_fuses_upsum.restype = C.c_int
     lib.ssdn_conv_fuses_pool.argtypes = [C.c_void_p]

@@ -102,6 +102,8 @@ def _upload(dn, it):
 def _out_of(op):
     a = op.a
     if op.type == "conv":
+        if a.get("unrot") is not None:          # fused UNROT_BWD: the launch's only output
+            return ("act", a["unrot"], a["M"] // 4)
         return ("f32", a["dst32"], None) if a["dst32"] is not None else ("act", a["dst"], a["M"])
     if op.type == "pool_fwd":
         return ("act", a["pooled"], a["C"])

@@ -1,26 +1,63 @@
 #!/bin/bash
-# HBM-side traffic of the k_conv<3> launches of the bench workload: separate FETCH_SIZE / WRITE_SIZE passes (run via gpurun)
+# HBM-side traffic of the bench workload per kernel family: separate FETCH_SIZE / WRITE_SIZE passes (run via gpurun).
+# Writes gpurun_out/pmc_traffic/traffic.json (copy to profiles/rNN_traffic.json): bytes per launch of k_cdma<3,*> (the roofline
+# kernel of bench.py) and per-step totals of every family.  FETCH_SIZE is doubled as MI355X_MICROARCH.md (HBM section) prescribes.
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_traffic
-mkdir -p $OUT
+rm -rf $OUT; mkdir -p $OUT
 cd /tmp
+STEPS=4; WARM=2
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 250 rocprofv3 --pmc $c --kernel-trace -d $OUT/$c -o t --output-format csv -- python $R/bench.py --steps 4 --warmup 2 --no-cpu-baseline > $OUT/$c.log 2>&1
-  f=$(find $OUT/$c -name "*counter_collection.csv" | head -1)
-  echo "== $c ($f)"
-  python - "$f" <<'PY'
-import csv, sys, collections
-rows = list(csv.DictReader(open(sys.argv[1])))
-acc = collections.defaultdict(list)
-for r in rows:
-    k = r.get("Kernel_Name", "")
-    if "k_conv<3" in k:
-        acc["k_conv<3,*> (all)"].append(float(r["Counter_Value"]))
-    if "k_conv" in k or "k_wgrad" in k:
-        acc[k.split("(")[0][:44]].append(float(r["Counter_Value"]))
-for k, v in sorted(acc.items()):
-    print("%-46s launches %5d  mean %12.1f  sum %14.1f" % (k, len(v), sum(v) / len(v), sum(v)))
-PY
+  timeout 250 rocprofv3 --pmc $c --kernel-trace -d $OUT/$c -o t --output-format csv -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > $OUT/$c.log 2>&1
 done
+python - "$OUT" $STEPS $WARM <<'PY'
+import csv, sys, glob, collections, json, re, subprocess, datetime
+out, steps, warm = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+def family(k):
+    k = k.split("(")[0]
+    m = re.match(r"(?:void )?(k_\w+)(<[^>]*>)?", k)
+    if not m: return None
+    name, t = m.group(1), m.group(2) or ""
+    if name == "k_cdma": return "k_cdma<3,*>" if t.startswith("<3") else "k_cdma<2|1,*>"
+    if name in ("k_conv", "k_gdma", "k_wgrad", "k_wgrad_multi"): return name
+    if name.startswith("k_wreduce"): return "k_wreduce*"
+    return "elementwise/head/adam"
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(out + "/" + c + "/**/*counter_collection.csv", recursive=True)
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(f[0])):
+        fam = family(r.get("Kernel_Name", ""))
+        if fam: acc[fam].append(float(r["Counter_Value"]))
+    res[c] = acc
+fams = sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]))
+nsteps_profiled = None
+table = {}
+for fam in fams:
+    fv, wv = res["FETCH_SIZE"].get(fam, []), res["WRITE_SIZE"].get(fam, [])
+    n = max(len(fv), len(wv))
+    fetch_kb, write_kb = sum(fv), sum(wv)
+    table[fam] = {"launches": n, "fetch_kb_raw_sum": round(fetch_kb, 1), "write_kb_sum": round(write_kb, 1),
+                  "hbm_bytes_per_launch": int((2.0 * fetch_kb + write_kb) * 1024 / max(1, n))}
+# steps seen by the profiler = launches of k_cdma<3,*> / 8
+nst = table.get("k_cdma<3,*>", {}).get("launches", 0) / 8.0
+for fam in table:
+    table[fam]["hbm_mb_per_step"] = round(table[fam]["hbm_bytes_per_launch"] * table[fam]["launches"] / max(1e-9, nst) / 1e6, 1)
+commit = ""
+try:
+    commit = open(out + "/../../COMMIT").read().strip()
+except OSError:
+    pass
+j = {"kernel": "k_cdma<3,*> (every launch of the bench workload: decode_block_1.*/2.* forward + data gradient)",
+     "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --steps %d --warmup %d --no-cpu-baseline (two separate passes, tools/pmc_traffic.sh)" % (steps, warm),
+     "hbm_bytes_per_launch": table.get("k_cdma<3,*>", {}).get("hbm_bytes_per_launch"),
+     "fetch_correction": 2.0, "steps_profiled": nst,
+     "families": table,
+     "total_hbm_mb_per_step": round(sum(t["hbm_mb_per_step"] for t in table.values()), 1),
+     "collected_at": "round 2, " + datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),
+     "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16 B/lane coalesced reads on gfx950; WRITE_SIZE as reported (calibrated in round 1 on the weight-gradient slabs). Infinity-Cache hits are counted, not excluded."}
+json.dump(j, open(out + "/traffic.json", "w"), indent=1)
+print(json.dumps(j, indent=1))
+PY
