@@ -626,9 +626,10 @@ struct WgMultiEntry {
     int first, gx, gy, inst;
 };
 #define WG_MULTI_INSTANCES(X) \
-    X(0, 2, 1, 4, false) X(1, 2, 2, 4, false) X(2, 2, 3, 4, false) \
-    X(4, 3, 1, 4, false) X(5, 3, 2, 4, false) X(6, 3, 3, 4, false) \
-    X(9, 3, 1, 6, true) X(10, 2, 1, 6, true)
+    X(0, 2, 1, 4, false) X(1, 2, 2, 4, false) X(2, 2, 3, 4, false) X(3, 2, 5, 4, false) \
+    X(4, 3, 1, 4, false) X(5, 3, 2, 4, false) X(6, 3, 3, 4, false) X(7, 3, 4, 4, false) X(8, 3, 5, 4, false) \
+    X(9, 3, 1, 6, true) X(10, 2, 1, 6, true) X(11, 3, 2, 6, true) X(12, 3, 4, 6, true) X(13, 2, 3, 6, true) \
+    X(16, 2, 5, 6, true) X(17, 3, 5, 6, true) X(18, 3, 3, 6, true) X(19, 2, 2, 6, true)
 __global__ __launch_bounds__(WG_THREADS) void k_wgrad_multi(const WgMultiEntry* __restrict__ tab, int n) {
     int e = 0;
     while (e + 1 < n && (int)blockIdx.x >= tab[e + 1].first) ++e;

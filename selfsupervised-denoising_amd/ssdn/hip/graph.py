@@ -347,6 +347,8 @@ class NetPlan:
         def candidate(G):
             cpw = -(-ctiles // (4 * G))
             cus_eff = max(1, self.cus // G)
+            if small and small_g > 0:
+                cus_eff = max(1, min(self.cus, small_cus) // G)
             if mblocks > 1 and not os.environ.get("SSDN_HEAD_FULL_SLABS"):
                 # the mblocks workgroups of a pixel partition run side by side: cus / mblocks partitions fill the chip in ONE
                 # round with 1/mblocks of the slab traffic (output_block.0: 38 MB instead of 151 MB written and read back)
@@ -359,15 +361,28 @@ class NetPlan:
 
         best = None
         groups = [1] if (mblocks > 1 or os.environ.get("SSDN_NO_CSPLIT")) else sorted({1, 2, 3, 4, -(-ctiles // 4)})
-        for G in groups:
-            if G > 1 and 4 * -(-ctiles // (4 * G)) * (G - 1) >= ctiles:
-                continue                      # the last group would be empty
-            try:
-                t, tile_g, ns_g = candidate(G)
-            except ValueError:                # no tile the fewer, fatter workgroups could prefetch
-                continue
-            if best is None or t < 0.9 * best[0]:        # a split must pay clearly
-                best = (t, G, tile_g, ns_g)
+        # Layers of at most 32768 pixels run inside ONE merged launch per gradient bucket (k_wgrad_multi) and get their
+        # parallelism from each other: two column groups on 32 pixel partitions each (a few tiles per workgroup) instead of
+        # up to seven groups that every one stage the same tiles -- measured on BASELINE config 2: -85 us per step against the
+        # per-layer optimum (G = 1 on 32..64 partitions is equal within noise but needs the 21-accumulator instances).
+        small = N * H * W <= 32768 and mblocks == 1 and cblocks is None and not os.environ.get("SSDN_NO_WGRAD_GROUPS")
+        small_g = int(os.environ.get("SSDN_SMALL_WGRAD_G", "2"))
+        small_cus = int(os.environ.get("SSDN_SMALL_WGRAD_CUS", "64"))
+        default_groups = list(groups)
+        if small and small_g > 0:
+            groups = [small_g]
+        for attempt in (groups, default_groups):
+            for G in attempt:
+                if G > 1 and 4 * -(-ctiles // (4 * G)) * (G - 1) >= ctiles:
+                    continue                      # the last group would be empty
+                try:
+                    t, tile_g, ns_g = candidate(G)
+                except ValueError:                # no tile the fewer, fatter workgroups could prefetch
+                    continue
+                if best is None or t < 0.9 * best[0]:        # a split must pay clearly
+                    best = (t, G, tile_g, ns_g)
+            if best is not None:
+                break
         _, G, (ltw, lth, ltn), nslabs = best
         csplit = G if G > 1 else 0
         # every weight-gradient launch owns its slab (1.2 GB in total for BASELINE config 2 -- 0.4 % of the 288 GB of HBM): no
