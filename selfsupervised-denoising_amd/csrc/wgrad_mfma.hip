@@ -15,6 +15,7 @@
 // SSDN_OP_WREDUCE sums the slabs in a fixed order => bit-reproducible gradients.
 #include "common.h"
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <utility>
@@ -742,7 +743,8 @@ static int wgrad_multi_inst(const WgPrep& p) {
 }
 bool wgrad_mergeable(const ssdn_wgrad_args* a) {
     // layers of at most 128 images x 16 x 16 pixels: their own launch cannot fill the chip
-    if ((long long)a->N * a->H * a->W > 32768 || a->mblocks > 1) return false;
+    static const long long small_px = [] { const char* e = getenv("SSDN_WGRAD_SMALL_PX"); return e ? atoll(e) : 32768ll; }();   // experiment knob, read once
+    if ((long long)a->N * a->H * a->W > small_px || a->mblocks > 1) return false;
     WgPrep p;
     if (wgrad_validate(a)) return false;
     p.g = wg_geom(*a);

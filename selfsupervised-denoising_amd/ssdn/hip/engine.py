@@ -112,7 +112,7 @@ class DeviceNet:
         # The weight-gradient GEMMs of the layers at 16x16 pixels and below are issued together, where the last of them
         # stood: the executor runs a run of consecutive small SSDN_OP_WGRAD ops as ONE launch (k_wgrad_multi; same rule as
         # csrc/wgrad_mfma.hip::wgrad_mergeable).  Legal for the same reason: a side-lane op may always be delayed.
-        small = lambda op: op.type == "wgrad" and op.a["N"] * op.a["H"] * op.a["W"] <= 32768 and not os.environ.get("SSDN_NO_WGRAD_GROUPS")  # noqa: E731
+        small = lambda op: op.type == "wgrad" and op.a["N"] * op.a["H"] * op.a["W"] <= int(os.environ.get("SSDN_WGRAD_SMALL_PX", "32768")) and not os.environ.get("SSDN_NO_WGRAD_GROUPS")  # noqa: E731
         # (one run per gradient bucket, so that a bucket still completes where it did)
         flush_at = {}                                   # index of the last small wgrad of each bucket
         for i, op in enumerate(plan.bwd):

@@ -346,13 +346,19 @@ class NetPlan:
 
         def candidate(G):
             cpw = -(-ctiles // (4 * G))
-            cus_eff = max(1, self.cus // G)
+            # A weight-gradient workgroup owns its CU (one wave per SIMD with the whole register file, ~135 KB of LDS): a launch
+            # with one workgroup per CU leaves the data-gradient lane nothing to run on until it drains.  Planning the
+            # persistent grids for 3/4 of the CUs keeps both lanes running side by side (measured on BASELINE config 2, two
+            # boxes: 256 -> 2.35 ms, 208 -> 2.35, 192 -> 2.27 / 2.30, 160 -> 2.29, 128 -> 2.29 ms per step) and trims the slab
+            # traffic by a quarter.
+            wcus = int(os.environ.get("SSDN_WGRAD_CUS", 0)) or (self.cus if self.cus < 64 else (3 * self.cus // 4) & ~7)
+            cus_eff = max(1, wcus // G)
             if small and small_g > 0:
                 cus_eff = max(1, min(self.cus, small_cus) // G)
             if mblocks > 1 and not os.environ.get("SSDN_HEAD_FULL_SLABS"):
                 # the mblocks workgroups of a pixel partition run side by side: cus / mblocks partitions fill the chip in ONE
                 # round with 1/mblocks of the slab traffic (output_block.0: 38 MB instead of 151 MB written and read back)
-                cus_eff = max(1, self.cus // mblocks)
+                cus_eff = max(1, wcus // mblocks)
             tile, ntiles = choose_wgrad_tile(N, H, W, taps, max(Kpad, Ktot), Mpad, Ktot, Mz, cus_eff)
             ns = max(1, min(ntiles, cus_eff))
             ksteps = (1 << sum(tile)) // 16
@@ -365,7 +371,8 @@ class NetPlan:
         # parallelism from each other: two column groups on 32 pixel partitions each (a few tiles per workgroup) instead of
         # up to seven groups that every one stage the same tiles -- measured on BASELINE config 2: -85 us per step against the
         # per-layer optimum (G = 1 on 32..64 partitions is equal within noise but needs the 21-accumulator instances).
-        small = N * H * W <= 32768 and mblocks == 1 and cblocks is None and not os.environ.get("SSDN_NO_WGRAD_GROUPS")
+        small = N * H * W <= int(os.environ.get("SSDN_WGRAD_SMALL_PX", "32768")) and mblocks == 1 and cblocks is None and \
+            not os.environ.get("SSDN_NO_WGRAD_GROUPS")
         small_g = int(os.environ.get("SSDN_SMALL_WGRAD_G", "2"))
         small_cus = int(os.environ.get("SSDN_SMALL_WGRAD_CUS", "64"))
         default_groups = list(groups)

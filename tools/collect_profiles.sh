@@ -12,12 +12,14 @@ timeout 300 python $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/kt -o kt --output-format csv -- python $R/bench.py --steps 20 --warmup 5 --no-cpu-baseline > $OUT/kt.log 2>&1
 cp $(find $OUT/kt -name "*kernel_stats.csv" | head -1) $OUT/bench_kernel_stats.csv
 python $R/tools/timeline.py $(find $OUT/kt -name "*kernel_trace.csv" | head -1) 10 > $OUT/bench_timeline.txt 2>&1
-# 3. HBM-side traffic (separate passes)
+# 3. HBM-side traffic (separate passes), per kernel family
 bash $R/tools/pmc_traffic.sh > $OUT/traffic.txt 2>&1
-# 4. SQ counters of the two MFMA kernels on the full-resolution 96->96 3x3 layer
-bash $R/tools/pmc_wgrad.sh decode_block_1.2 fwd > $OUT/pmc_conv_fwd.txt 2>&1
-bash $R/tools/pmc_wgrad.sh decode_block_1.2 dgrad > $OUT/pmc_conv_dgrad.txt 2>&1
+cp $R/gpurun_out/pmc_traffic/traffic.json $OUT/traffic.json
+# 4. SQ counters of the MFMA kernels on the full-resolution 96->96 3x3 layer (k_cdma fwd / dgrad, k_wgrad) and the 384->384 head GEMM
+bash $R/tools/pmc_wgrad.sh decode_block_1.2 fwd > $OUT/pmc_cdma_fwd.txt 2>&1
+bash $R/tools/pmc_wgrad.sh decode_block_1.2 dgrad > $OUT/pmc_cdma_dgrad.txt 2>&1
 bash $R/tools/pmc_wgrad.sh decode_block_1.2 wgrad > $OUT/pmc_wgrad.txt 2>&1
+bash $R/tools/pmc_wgrad.sh output_block.0 fwd > $OUT/pmc_gdma_fwd.txt 2>&1
 # 5. per-launch timings in isolation
 timeout 200 python $R/tools/conv_bench.py all wgrad > $OUT/wgrad_isolated.txt 2>&1
 timeout 200 python $R/tools/conv_bench.py all conv > $OUT/conv_isolated.txt 2>&1

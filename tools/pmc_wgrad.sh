@@ -1,5 +1,5 @@
 #!/bin/bash
-# SQ counter passes over one weight-gradient launch (measurement aid; run through gpurun)
+# SQ counter passes over one MFMA-kernel launch: tools/pmc_wgrad.sh <layer> <fwd|dgrad|wgrad> (measurement aid; run through gpurun)
 set -u
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -19,7 +19,7 @@ rows = list(csv.DictReader(open(f)))
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in rows:
     k = r.get("Kernel_Name", "")
-    if "k_wgrad" in k or "k_conv" in k:
+    if "k_wgrad" in k or "k_conv" in k or "k_cdma" in k or "k_gdma" in k:
         acc[k[:60]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k, {c: (len(v), sum(v) / len(v)) for c, v in d.items()})
