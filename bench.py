@@ -202,7 +202,7 @@ def main():
                               "ms_per_step_bracketed_sum": round(m2.value * FAM_STRIDE / FAM_STEPS, 4)}
     # (b) the same loop with the minibatch arriving from (pinned) host memory every step: the PCIe-inclusive rate of
     # SURVEY.md section 8(d); reported next to `value`, never as `value`
-    h2d_value = None
+    h2d_value = u8_value = None
     if world == 1:
         host = [[b[0].cpu().pin_memory(), b[1].cpu().pin_memory(),
                  {k: (v.cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in b[2].items()}] for b in batches]
@@ -216,6 +216,22 @@ def main():
                          3e-4, exchange)
         torch.cuda.synchronize()
         h2d_value = round(nh * B / (time.perf_counter() - th0), 2)
+        # (c) N2: the minibatch arrives as the CLEAN uint8 patches (393 KB) and noise / metadata are produced on the device
+        # (ssdn.datasets.DevicePatchStream.prepare -- what DenoiserTrainer does on a GPU)
+        from ssdn.datasets import DevicePatchStream, NoisyDataset
+        from ssdn.params import NoiseAlgorithm
+        nd = NoisyDataset(None, "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
+        stream = DevicePatchStream(None, nd, device, seed=1)
+        u8 = [(b[2][NoisyDataset.Metadata.CLEAN].cpu() * 255).round().to(torch.uint8).pin_memory() for b in batches]
+        idx = torch.arange(B)
+        for i in range(3):
+            d.train_step(stream.prepare(u8[i % len(u8)], idx), 3e-4, exchange)
+        torch.cuda.synchronize()
+        tu0 = time.perf_counter()
+        for i in range(nh):
+            d.train_step(stream.prepare(u8[i % len(u8)], idx), 3e-4, exchange)
+        torch.cuda.synchronize()
+        u8_value = round(nh * B / (time.perf_counter() - tu0), 2)
 
     if rank == 0:
         value = args.steps * B * world / dt
@@ -252,6 +268,7 @@ def main():
         res["families"] = families
         if h2d_value is not None:
             res["value_with_h2d"] = h2d_value
+            res["value_with_device_patch_stream"] = u8_value
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(res))

@@ -34,7 +34,7 @@ from torch.utils.data import DataLoader
 
 import ssdn
 from ssdn.cfg import DEFAULT_RUN_DIR
-from ssdn.datasets import FixedLengthSampler, HDF5Dataset, NoisyDataset, SamplingOrder, UnlabelledImageFolderDataset
+from ssdn.datasets import CleanPatches, DevicePatchStream, FixedLengthSampler, HDF5Dataset, NoisyDataset, SamplingOrder, UnlabelledImageFolderDataset
 from ssdn.datasets.transforms import RandomCrop
 from ssdn.denoiser import Denoiser
 from ssdn.models import NoiseNetwork
@@ -86,6 +86,7 @@ class DenoiserTrainer:
         from ssdn.hip import dp
         self.rank, self.world, self.local_rank = dp.env_world()
         self._exchange = None
+        self.device_data = None          # None: device-side patch preparation whenever a GPU is present (see train_data)
 
     # ---- target -----------------------------------------------------------------------------------------------------------
     @property
@@ -409,13 +410,24 @@ class DenoiserTrainer:
             sampler.for_next_iter(order)
             self._train_iter = None
         kw = dict(num_workers=cfg[ConfigValue.DATALOADER_WORKERS], pin_memory=cfg[ConfigValue.PIN_DATA_MEMORY] or torch.cuda.is_available())
+        # N2: on a GPU the workers ship the clean patch as uint8 and the per-sample noise / Noise2Void manipulation / metadata
+        # are produced for the whole minibatch on the device (ssdn.datasets.device_stream); SSDN_HOST_DATA=1 keeps the
+        # reference's host-side preparation
+        device_stream = (self.device_data if self.device_data is not None else
+                         (torch.cuda.is_available() and not os.environ.get("SSDN_HOST_DATA"))) and \
+            cfg[ConfigValue.TRAIN_PATCH_SIZE] % NoiseNetwork.input_wh_mul() == 0
+        source = CleanPatches(dataset) if device_stream else dataset
         if self.world > 1:
             _ = iter(sampler)                        # materialise the order under the common seed, then reuse it
             sampler.for_next_iter(sampler.last_iter())
             torch.set_rng_state(g)
-            loader = DataLoader(dataset, batch_sampler=_RankShard(sampler, cfg[ConfigValue.TRAIN_MINIBATCH_SIZE], self.rank, self.world), **kw)
+            loader = DataLoader(source, batch_sampler=_RankShard(sampler, cfg[ConfigValue.TRAIN_MINIBATCH_SIZE], self.rank, self.world), **kw)
         else:
-            loader = DataLoader(dataset, sampler=sampler, batch_size=cfg[ConfigValue.TRAIN_MINIBATCH_SIZE], **kw)
+            loader = DataLoader(source, sampler=sampler, batch_size=cfg[ConfigValue.TRAIN_MINIBATCH_SIZE], **kw)
+        if device_stream:
+            dev = self.denoiser.device if self.denoiser is not None and hasattr(self.denoiser, "device") else \
+                torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+            loader = DevicePatchStream(loader, dataset, dev)
         return loader, dataset, sampler
 
     def set_train_data(self, path: str):

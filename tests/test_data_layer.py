@@ -198,3 +198,59 @@ def test_random_crop_pads_small_images_by_reflection():
     assert crop(big).size == (64, 64)
     small = Image.fromarray(np.random.RandomState(1).randint(0, 255, (20, 70, 3)).astype(np.uint8))
     assert crop(small).size == (64, 64)
+
+
+class _Patches(torch.utils.data.Dataset):
+    """child dataset: 8-bit CHW patches as floats in [0,1] (what UnlabelledImageFolderDataset / HDF5Dataset + RandomCrop return)"""
+
+    def __init__(self, n=24, P=32, seed=3):
+        g = torch.Generator().manual_seed(seed)
+        self.x = torch.randint(0, 256, (n, 3, P, P), generator=g).float() / 255.0
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        return self.x[i], i
+
+
+@pytest.mark.parametrize("alg,style", [(NoiseAlgorithm.SELFSUPERVISED_DENOISING, "gauss25"), (NoiseAlgorithm.NOISE_TO_NOISE, "poisson30"),
+                                        (NoiseAlgorithm.NOISE_TO_VOID, "gauss5_50"), (NoiseAlgorithm.NOISE_TO_CLEAN, "gauss25")])
+def test_device_patch_stream_matches_the_host_pipeline(alg, style):
+    """N2: the batch-on-device preparation yields what a DataLoader over NoisyDataset yields -- same keys, shapes, dtypes, exact
+    clean patches, the same noise distribution (it cannot be the same random stream).  Runs on CPU tensors here."""
+    from torch.utils.data import DataLoader
+    from ssdn.datasets import CleanPatches, DevicePatchStream
+    MD = NoisyDataset.Metadata
+    child = _Patches()
+    ds = NoisyDataset(child, style, alg, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
+    host = next(iter(DataLoader(ds, batch_size=8, shuffle=False)))
+    stream = DevicePatchStream(DataLoader(CleanPatches(ds), batch_size=8, shuffle=False), ds, "cpu", seed=5)
+    dev = next(iter(stream))
+    assert len(dev) == len(host) == 3
+    for a, b in ((host[0], dev[0]), (host[1], dev[1])):
+        assert a.shape == b.shape and a.dtype == b.dtype
+    assert set(host[2].keys()) == set(dev[2].keys())
+    for k in host[2]:
+        assert host[2][k].shape == dev[2][k].shape and host[2][k].dtype == dev[2][k].dtype, k
+    assert torch.equal(dev[2][MD.CLEAN], host[2][MD.CLEAN])              # uint8 round trip is exact
+    assert torch.equal(dev[2][MD.INDEXES], host[2][MD.INDEXES]) and torch.equal(dev[2][MD.IMAGE_SHAPE], host[2][MD.IMAGE_SHAPE])
+    # noise statistics over a few batches (un-clipped residual would need the un-clipped image: compare the two pipelines)
+    def residual_stats(batches):
+        r = torch.cat([(b[0] - b[2][MD.CLEAN]).flatten() for b in batches])
+        return float(r.mean()), float(r.std())
+    hb = [b for b in DataLoader(ds, batch_size=8, shuffle=False)]
+    db = [b for b in stream]
+    (hm, hs), (dm, dsd) = residual_stats(hb), residual_stats(db)
+    assert abs(hm - dm) < 6e-3 and abs(hs - dsd) < 0.1 * hs + 1e-3, (hm, hs, dm, dsd)
+    if style == "gauss25":
+        assert torch.allclose(dev[2][MD.INPUT_NOISE_VALUES], torch.full((8, 1, 1, 1), 25 / 255.0))
+    if style == "gauss5_50":            # one sigma per sample AND channel (the reference's draw), inside the range
+        s = dev[2][MD.INPUT_NOISE_VALUES].flatten()
+        assert float(s.min()) >= 5 / 255 and float(s.max()) <= 50 / 255 and len(set(s.tolist())) > 1
+    if alg == NoiseAlgorithm.NOISE_TO_VOID:
+        c = dev[2][MD.MASK_COORDS]
+        assert c.dtype == torch.int64 and c.shape == host[2][MD.MASK_COORDS].shape
+        # every manipulated pixel took its value from the reference's window around it ([0, c + r] clipped, not the pixel itself)
+        noisy_ref = dev[1]                                                 # (independent noise: only the geometry is checked)
+        assert int(c.min()) >= 0 and int(c[..., 0].max()) < 32 and int(c[..., 1].max()) < 32
