@@ -39,6 +39,7 @@ def test_cli_train_resume_eval_round_trip(tmp_path):
     _make_folder(data, 6, 0)
     _make_folder(val, 2, 1)
     runs = str(tmp_path / "runs")
+    torch.manual_seed(20260929)          # weights, sampling order and the device noise stream all derive from the host RNG
     trainer = start_cli(["train", "start", "-a", "ssdn", "-n", "gauss25", "--noise_value", "known", "-t", data, "-v", val,
                          "-i", "192", "--train_batch_size", "8", "--validation_batch_size", "2", "--patch_size", "32",
                          "--eval_interval", "96", "--print_interval", "48", "--checkpoint_interval", "96", "--runs_dir", runs])
