@@ -36,7 +36,8 @@ __device__ __forceinline__ f32x16 gd_mma(half8 av, half8 bv, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
 }
 
-constexpr int GD_DA = 5, GD_DB = 3;
+constexpr int GD_DA = 3, GD_DB = 3;
+constexpr int gd_eg(int wm) { return wm == 6 ? 2 : wm; }       // channel tiles per epilogue transpose group
 
 // wait until all but the newest n groups of PER DMA instructions of this wave have landed
 template <int PER>
@@ -51,25 +52,30 @@ __device__ __forceinline__ void gd_wait_groups(int n) {
 }  // namespace
 
 // wave grid NWP (pixels) x NWM (channels); a wave owns WP x 32 pixels and WM x 32 output channels.  EPI bit 0: LeakyReLU' mask;
-// bit 1: fused SSDN_OP_UNROT_BWD (the 96-channel block r of a pixel goes, times LeakyReLU', to its place in rotation r's tensor)
+// bit 1: fused SSDN_OP_UNROT_BWD (the 96-channel block r of a pixel goes, times LeakyReLU', to its place in rotation r's tensor).
+// PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the two operand rings run on as one chunk stream
+// across tile boundaries, so the loads of tile i+1 are in flight while tile i is converted and stored (the epilogue has its own
+// LDS region: wave-private transposes of EG channel tiles at a time).
 template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
 __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, GdAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NW = NWP * NWM, TP = NWP * WP * 32, TM = NWM * WM * 32;
     constexpr int ABYTES = TP * 64, BBYTES = TM * 64;
-    constexpr int DA = GD_DA, DB = GD_DB;                    // ring depths: activation chunks (HBM latency) / weight chunks (L2)
+    constexpr int DA = GD_DA, DB = GD_DB;                    // ring depths: activation chunks (HBM) / weight chunks (L2)
     constexpr int NLA = NW / 2, NLB = NW - NLA;              // loader roles: waves [0, NLA) fetch activations, the rest weights --
-                                                             // vmcnt completes in order per WAVE, so the deep activation
-                                                             // prefetch must not share a counter with the shallow weight stream
+                                                             // vmcnt completes in order per WAVE: two streams, two counters
     constexpr int NIA = TP / 16, NIB = TM / 16, PA = (NIA + NLA - 1) / NLA, PB = (NIB + NLB - 1) / NLB;
-    constexpr int BOFF = DA * ABYTES, BIAS_OFF = BOFF + DB * BBYTES, DUMMY_OFF = BIAS_OFF + TM * 4;
-    constexpr int OSTR = WM * 64 + 16, NEK = WM * 2, CPP = WM * 4;
+    constexpr int EG = gd_eg(WM), NEG = WM / EG;             // epilogue: channel tiles per transpose group
+    constexpr int OSTR = EG * 64 + 16, NEK = EG * 2, CPP = EG * 4;
+    constexpr int BOFF = DA * ABYTES, EOFF = BOFF + DB * BBYTES, BIAS_OFF = EOFF + NW * 32 * OSTR, DUMMY_OFF = BIAS_OFF + TM * 4;
     constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / NWM, wm = w - wp * NWM;
     const unsigned lds0 = (unsigned)(size_t)smem;
-    const int pix0 = blockIdx.x * TP;
+    const int G = gridDim.x;
+    const int ntl = (x.ntiles - (int)blockIdx.x + G - 1) / G;        // tiles of this workgroup
+    const int total = ntl * x.nch;                                   // its chunk stream
 
     const unsigned long long ap = (unsigned long long)a.src0.p, wgp = (unsigned long long)a.w;
     const u32x4_t rs_a = {(unsigned)ap, (unsigned)(ap >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
@@ -83,175 +89,176 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     const int drow = lane >> 2, dpiece = (lane & 3) ^ ((drow >> 2) & 3);
     const int voffA = (drow * a.src0.cs + dpiece * 8) * 2;
     const int voffB = (drow * a.Ktot + dpiece * 8) * 2;
-    const int sA0 = ((pix0 * a.src0.cs) + a.src0.co) * 2;
     const bool loadA = w < NLA;
-    auto issueA = [&](int c, int st) __attribute__((always_inline)) {
+    // loader state: the next chunk to issue is chunk lc of this workgroup's tile lt, into stage lst
+    int lt = 0, lc = 0, lst = 0, issued = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (loadA) {
+            const int pix0 = ((int)blockIdx.x + lt * G) * TP;
 #pragma unroll
-        for (int u = 0; u < PA; ++u) {
-            const int i = w + NLA * u;              // wave-uniform
-            if (i < NIA) {
-                const int soff = __builtin_amdgcn_readfirstlane(sA0 + (i * 16 * a.src0.cs + c * 32) * 2);
-                gd_dma16(lds0 + st * ABYTES + i * 1024, voffA, rs_a, soff);
-            } else {
-                // keep every loader's DMA count per chunk equal (one vmcnt immediate per role): an out-of-range fetch that
-                // drops zeros into a scratch KiB
-                gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+            for (int u = 0; u < PA; ++u) {
+                const int i = w + NLA * u;              // wave-uniform
+                if (i < NIA) {
+                    const int soff = __builtin_amdgcn_readfirstlane((((pix0 + i * 16) * a.src0.cs) + a.src0.co + lc * 32) * 2);
+                    gd_dma16(lds0 + lst * ABYTES + i * 1024, voffA, rs_a, soff);
+                } else {
+                    // keep every loader's DMA count per chunk equal (one vmcnt immediate per role): an out-of-range fetch that
+                    // drops zeros into a scratch KiB
+                    gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+                }
             }
-        }
-    };
-    auto issueB = [&](int c, int st) __attribute__((always_inline)) {
+            lst = lst == DA - 1 ? 0 : lst + 1;
+        } else {
 #pragma unroll
-        for (int u = 0; u < PB; ++u) {
-            const int j = (w - NLA) + NLB * u;
-            if (j < NIB) {
-                const int soff = __builtin_amdgcn_readfirstlane((j * 16 * a.Ktot + c * 32) * 2);
-                gd_dma16(lds0 + BOFF + st * BBYTES + j * 1024, voffB, rs_w, soff);
-            } else {
-                gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+            for (int u = 0; u < PB; ++u) {
+                const int j = (w - NLA) + NLB * u;
+                if (j < NIB) {
+                    const int soff = __builtin_amdgcn_readfirstlane((j * 16 * a.Ktot + lc * 32) * 2);
+                    gd_dma16(lds0 + BOFF + lst * BBYTES + j * 1024, voffB, rs_w, soff);
+                } else {
+                    gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+                }
             }
+            lst = lst == DB - 1 ? 0 : lst + 1;
         }
+        ++issued;
+        if (++lc == x.nch) { lc = 0; ++lt; }
     };
-
-    if (loadA) {
-        for (int c = 0; c < DA - 1 && c < x.nch; ++c) issueA(c, c);
-    } else {
-        for (int c = 0; c < DB - 1 && c < x.nch; ++c) issueB(c, c);
-    }
+    const int lead = loadA ? DA - 1 : DB - 1;
+    for (int c = 0; c < lead && c < total; ++c) issue_next();
     float* bl = reinterpret_cast<float*>(smem + BIAS_OFF);
     if (tid < TM) bl[tid] = (a.bias && tid < a.M) ? a.bias[tid] : 0.f;
     __syncthreads();
-
-    f32x16 acc[WM][WP];
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const float4 b4 = *reinterpret_cast<const float4*>(bl + (wm * WM + mt) * 32 + 8 * g + 4 * kh);
-#pragma unroll
-            for (int pt = 0; pt < WP; ++pt) {
-                acc[mt][pt][4 * g + 0] = b4.x; acc[mt][pt][4 * g + 1] = b4.y; acc[mt][pt][4 * g + 2] = b4.z; acc[mt][pt][4 * g + 3] = b4.w;
-            }
-        }
 
     // fragment addresses: row l31 of a 32-row block, K half kh of K-step s -> piece (2s + kh) ^ ((l31 >> 2) & 3)
     const int sw = (l31 >> 2) & 3;
     const int fr0 = l31 * 64 + ((kh ^ sw) << 4), fr1 = l31 * 64 + (((2 + kh) ^ sw) << 4);
     const int pbase = wp * WP * 2048, mbase = BOFF + wm * WM * 2048;
-
-    auto compute = [&](int sa, int sb_) __attribute__((always_inline)) {
-        const char* pa = smem + sa * ABYTES + pbase;
-        const char* pb = smem + sb_ * BBYTES + mbase;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const int fr = s ? fr1 : fr0;
-            half8 pq[WP], wq[WM];
-#pragma unroll
-            for (int pt = 0; pt < WP; ++pt) pq[pt] = *reinterpret_cast<const half8*>(pa + pt * 2048 + fr);
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt) wq[mt] = *reinterpret_cast<const half8*>(pb + mt * 2048 + fr);
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                for (int pt = 0; pt < WP; ++pt) acc[mt][pt] = gd_mma<BF>(wq[mt], pq[pt], acc[mt][pt]);
-        }
-    };
-
-    // ---- main loop: chunk c sits in activation stage c % DA and weight stage c % DB; a loader keeps D-1 chunks ahead ----
-    int ca = 0, cb = 0;                 // stages of chunk c
-    int ia = DA - 1, ib = DB - 1;       // stages the loaders fill next (chunk c + D - 1)
-    for (int c = 0; c < x.nch; ++c) {
-        const int left = x.nch - 1 - c;
-        if (loadA) gd_wait_groups<PA>(left < DA - 2 ? left : DA - 2);
-        else gd_wait_groups<PB>(left < DB - 2 ? left : DB - 2);
-        __syncthreads();
-        if (loadA) { if (c + DA - 1 < x.nch) issueA(c + DA - 1, ia); }
-        else { if (c + DB - 1 < x.nch) issueB(c + DB - 1, ib); }
-        compute(ca, cb);
-        ca = ca == DA - 1 ? 0 : ca + 1; ia = ia == DA - 1 ? 0 : ia + 1;
-        cb = cb == DB - 1 ? 0 : cb + 1; ib = ib == DB - 1 ? 0 : ib + 1;
-    }
-    __syncthreads();      // every wave is done with the stages: they become the epilogue's transpose regions
-
     const float slope = a.act ? LRELU_SLOPE : 1.f;
-    char* reg = smem + w * (32 * OSTR);
-#pragma unroll
-    for (int pt = 0; pt < WP; ++pt) {
-        const int pix_p = pix0 + (wp * WP + pt) * 32;
+    char* reg = smem + EOFF + w * (32 * OSTR);
+
+    int ca = 0, cb = 0, done = 0;       // stages of the chunk being consumed; chunks consumed so far
+    for (int ti = 0; ti < ntl; ++ti) {
+        const int pix0 = ((int)blockIdx.x + ti * G) * TP;
+        f32x16 acc[WM][WP];
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-            for (int gp = 0; gp < 2; ++gp) {
-                unsigned pk[2][2];
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bl + (wm * WM + mt) * 32 + 8 * g + 4 * kh);
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    float v[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        v[j] = acc[mt][pt][(2 * gp + h) * 4 + j];
-                        v[j] = fmaxf(v[j], slope * v[j]);
-                    }
-                    pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
-                    pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
-                }
-                u32x4_t o;
-#pragma unroll
-                for (int d = 0; d < 2; ++d) {
-                    auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
-                    o[d] = r[0]; o[2 + d] = r[1];
-                }
-                const int piece = mt * 4 + 2 * gp + kh;
-                *reinterpret_cast<u32x4_t*>(reg + l31 * OSTR + piece * 16) = o;
-            }
-        // LDS -> HBM: 32 pixels x CPP 16-byte pieces, pixel-contiguous
-#pragma unroll
-        for (int k0 = 0; k0 < NEK; k0 += 6) {
-            u32x4_t mb[6];
-            int goff[6], loff[6];
-            bool live[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                const int p = (k0 + k) * 64 + lane;
-                const int px = p / CPP, c16 = (p - px * CPP) << 4;
-                const int pix = pix_p + px;
-                loff[k] = px * OSTR + c16;
-                live[k] = true;
-                if constexpr (UNROT) {
-                    // (b, i, j) of the pixel (H == W == P, a power of two), rotation r of the piece's 96-channel block
-                    const int lp = x.lp, P = 1 << lp;
-                    const int j = pix & (P - 1), i = (pix >> lp) & (P - 1), b = pix >> (2 * lp);
-                    const int ch = wm * WM * 32 + (c16 >> 1);
-                    const int r = ch >= 288 ? 3 : (ch >= 192 ? 2 : (ch >= 96 ? 1 : 0)), cc = ch - r * 96;
-                    const int u = r == 0 ? i : (r == 1 ? P - 1 - j : (r == 2 ? P - 1 - i : j));
-                    const int v = r == 0 ? j : (r == 1 ? i : (r == 2 ? P - 1 - j : P - 1 - i));
-                    live[k] = u >= 1;                                  // u == 0: the shift cut it off -> zero row y = P-1
-                    const int dpix = (((((r * a.N + b) << lp) + (u >= 1 ? u - 1 : P - 1))) << lp) + v;
-                    goff[k] = (dpix * a.unrot.cs + a.unrot.co + cc) * 2;
-                    mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
-                } else {
-                    goff[k] = (pix * a.dst.cs + a.dst.co + wm * WM * 32) * 2 + c16;
-                    if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + wm * WM * 32) * 2 + c16, 0, 0);
+                for (int pt = 0; pt < WP; ++pt) {
+                    acc[mt][pt][4 * g + 0] = b4.x; acc[mt][pt][4 * g + 1] = b4.y; acc[mt][pt][4 * g + 2] = b4.z; acc[mt][pt][4 * g + 3] = b4.w;
                 }
             }
+        // ---- chunks of this tile: chunk g sits in stages g % DA / g % DB; the loaders keep D-1 chunks ahead of `done` ----
+        for (int c = 0; c < x.nch; ++c) {
+            const int left = total - 1 - done;
+            if (loadA) gd_wait_groups<PA>(left < DA - 2 ? left : DA - 2);
+            else gd_wait_groups<PB>(left < DB - 2 ? left : DB - 2);
+            __syncthreads();
+            if (issued < total) issue_next();
+            const char* pa = smem + ca * ABYTES + pbase;
+            const char* pb = smem + cb * BBYTES + mbase;
 #pragma unroll
-            for (int k = 0; k < 6; ++k) {
-                u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + loff[k]);
-                if constexpr (UNROT) {
-                    if (!live[k]) o = u32x4_t{0u, 0u, 0u, 0u};
-                }
-                if constexpr (HAS_MASK || UNROT) {
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int fr = s2 ? fr1 : fr0;
+                half8 pq[WP], wq[WM];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v0, v1;
-                        if constexpr (BF) { v0 = bf_lo(o[q]); v1 = bf_hi(o[q]); }
-                        else { v0 = f16_lo(o[q]); v1 = f16_hi(o[q]); }
-                        const int mlo = (int)(short)(mb[k][q] & 0xffffu), mhi = (int)mb[k][q] >> 16;
-                        v0 *= mlo > 0 ? 1.f : LRELU_SLOPE;
-                        v1 *= mhi > 0 ? 1.f : LRELU_SLOPE;
-                        o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
+                for (int pt = 0; pt < WP; ++pt) pq[pt] = *reinterpret_cast<const half8*>(pa + pt * 2048 + fr);
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) wq[mt] = *reinterpret_cast<const half8*>(pb + mt * 2048 + fr);
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                    for (int pt = 0; pt < WP; ++pt) acc[mt][pt] = gd_mma<BF>(wq[mt], pq[pt], acc[mt][pt]);
+            }
+            ca = ca == DA - 1 ? 0 : ca + 1;
+            cb = cb == DB - 1 ? 0 : cb + 1;
+            ++done;
+        }
+        // ---- epilogue of the tile (wave-private; the rings keep filling meanwhile) ----
+#pragma unroll
+        for (int pt = 0; pt < WP; ++pt) {
+            const int pix_p = pix0 + (wp * WP + pt) * 32;
+#pragma unroll
+            for (int eg = 0; eg < NEG; ++eg) {
+                const int chb = wm * WM * 32 + eg * EG * 32;       // first channel of the group
+#pragma unroll
+                for (int me = 0; me < EG; ++me)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int mt = eg * EG + me;
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[q] = acc[mt][pt][(2 * gp + h) * 4 + q];
+                                v[q] = fmaxf(v[q], slope * v[q]);
+                            }
+                            pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
+                            pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
+                        }
+                        u32x4_t o;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+                            o[d] = r[0]; o[2 + d] = r[1];
+                        }
+                        const int piece = me * 4 + 2 * gp + kh;
+                        *reinterpret_cast<u32x4_t*>(reg + l31 * OSTR + piece * 16) = o;
+                    }
+                // LDS -> HBM: 32 pixels x CPP 16-byte pieces, pixel-contiguous runs of EG * 64 bytes
+                u32x4_t mb[NEK];
+                int goff[NEK], loff[NEK];
+                bool live[NEK];
+#pragma unroll
+                for (int k = 0; k < NEK; ++k) {
+                    const int p = k * 64 + lane;
+                    const int px = p / CPP, c16 = (p - px * CPP) << 4;
+                    const int pix = pix_p + px;
+                    loff[k] = px * OSTR + c16;
+                    live[k] = true;
+                    if constexpr (UNROT) {
+                        // (b, i, j) of the pixel (H == W == P, a power of two), rotation r of the piece's 96-channel block
+                        const int lp = x.lp, P = 1 << lp;
+                        const int jx = pix & (P - 1), iy = (pix >> lp) & (P - 1), b = pix >> (2 * lp);
+                        const int ch = chb + (c16 >> 1);
+                        const int r = ch >= 288 ? 3 : (ch >= 192 ? 2 : (ch >= 96 ? 1 : 0)), cc = ch - r * 96;
+                        const int u = r == 0 ? iy : (r == 1 ? P - 1 - jx : (r == 2 ? P - 1 - iy : jx));
+                        const int v = r == 0 ? jx : (r == 1 ? iy : (r == 2 ? P - 1 - jx : P - 1 - iy));
+                        live[k] = u >= 1;                                  // u == 0: the shift cut it off -> zero row y = P-1
+                        const int dpix = (((((r * a.N + b) << lp) + (u >= 1 ? u - 1 : P - 1))) << lp) + v;
+                        goff[k] = (dpix * a.unrot.cs + a.unrot.co + cc) * 2;
+                        mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
+                    } else {
+                        goff[k] = (pix * a.dst.cs + a.dst.co + chb) * 2 + c16;
+                        if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + chb) * 2 + c16, 0, 0);
                     }
                 }
-                if constexpr (UNROT) __builtin_amdgcn_raw_buffer_store_b128(o, rs_ur, goff[k], 0, 0);
-                else __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+#pragma unroll
+                for (int k = 0; k < NEK; ++k) {
+                    u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + loff[k]);
+                    if constexpr (UNROT) {
+                        if (!live[k]) o = u32x4_t{0u, 0u, 0u, 0u};
+                    }
+                    if constexpr (HAS_MASK || UNROT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v0, v1;
+                            if constexpr (BF) { v0 = bf_lo(o[q]); v1 = bf_hi(o[q]); }
+                            else { v0 = f16_lo(o[q]); v1 = f16_hi(o[q]); }
+                            const int mlo = (int)(short)(mb[k][q] & 0xffffu), mhi = (int)mb[k][q] >> 16;
+                            v0 *= mlo > 0 ? 1.f : LRELU_SLOPE;
+                            v1 *= mhi > 0 ? 1.f : LRELU_SLOPE;
+                            o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
+                        }
+                    }
+                    if constexpr (UNROT) __builtin_amdgcn_raw_buffer_store_b128(o, rs_ur, goff[k], 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+                }
             }
         }
     }
@@ -275,14 +282,16 @@ bool gemm_dma_eligible(const ssdn_conv_args* a) {
     return true;
 }
 
-int gemm_dma_lds_bytes(const ssdn_conv_args* a) { const int tm = a->Mpad == 384 ? 384 : 96; return GD_DA * 256 * 64 + GD_DB * tm * 64 + tm * 4 + 1024; }
+int gemm_dma_lds_bytes(const ssdn_conv_args* a) {
+    const int tm = a->Mpad == 384 ? 384 : 96, eg = a->Mpad == 384 ? 2 : 3;
+    return GD_DA * 256 * 64 + GD_DB * tm * 64 + 8 * 32 * (eg * 64 + 16) + tm * 4 + 1024;
+}
 
 template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
 static int gd_launch(const ssdn_conv_args* a, hipStream_t s) {
     constexpr int TP = NWP * WP * 32, TM = NWM * WM * 32;
-    constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + TM * 4 + 1024;
-    static_assert(TP == 256, "gemm_dma_lds_bytes assumes 256-pixel tiles");
-    static_assert(NWP * NWM * 32 * (WM * 64 + 16) <= GD_DA * TP * 64 + GD_DB * TM * 64, "epilogue regions must fit in the rings");
+    constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + NWP * NWM * 32 * (gd_eg(WM) * 64 + 16) + TM * 4 + 1024;
+    static_assert(TP == 256 && NWP * NWM == 8, "gemm_dma_lds_bytes assumes 256-pixel tiles and 8 waves");
     static_assert(LDS <= 160 * 1024, "LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -297,7 +306,10 @@ static int gd_launch(const ssdn_conv_args* a, hipStream_t s) {
     x.ntiles = (int)(px / TP);
     const int kreal = a->kreal > 0 ? a->kreal : a->Ktot;
     prof_begin(SSDN_PROF_GEMM, s);
-    hipLaunchKernelGGL((k_gdma<WP, WM, NWP, NWM, BF, EPI>), dim3(x.ntiles), dim3(64 * NWP * NWM), LDS, s, *a, x);
+    int cus = ssdn_device_cus();
+    if (cus <= 0) cus = 256;
+    const int grid = x.ntiles < cus ? x.ntiles : cus;           // persistent: one workgroup per CU (LDS-bound occupancy)
+    hipLaunchKernelGGL((k_gdma<WP, WM, NWP, NWM, BF, EPI>), dim3(grid), dim3(64 * NWP * NWM), LDS, s, *a, x);
     prof_end(SSDN_PROF_GEMM, s, 2.0 * px * a->M * kreal, px * (a->c0 + a->M) * 2.0);
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;
