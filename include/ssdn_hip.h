@@ -224,6 +224,9 @@ typedef struct ssdn_wgrad_args {
                               view, slabs [b*nslabs, (b+1)*nslabs) of `slab` / `bslab`): grid = mblocks x nslabs workgroups,
                               the mblocks workgroups that stream the same pixels placed on one XCD so that the input tile
                               reaches HBM once (1x1 head layers: 4 blocks of 96) */
+    int32_t kreal;         /* real (un-padded) input channels among the Ktot slots, or 0 (unknown).  1..3 real channels under a
+                              3x3 window (the network's first layer and the image half of decode_block_1.0) are served by the
+                              im2col kernel k_wgrad_thin: 9 * kreal + 1 <= 32 GEMM columns instead of 9 x 32 */
 } ssdn_wgrad_args;
 
 /* ---- SSDN_OP_WREDUCE ------------------------------------------------------------------------

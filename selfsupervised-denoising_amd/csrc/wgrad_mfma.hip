@@ -741,7 +741,9 @@ static int wgrad_multi_inst(const WgPrep& p) {
 #undef WG_X
     return -1;
 }
+static bool wgrad_thin_ok(const ssdn_wgrad_args* a);
 bool wgrad_mergeable(const ssdn_wgrad_args* a) {
+    if (wgrad_thin_ok(a)) return false;                             // (has its own kernel)
     // layers of at most 128 images x 16 x 16 pixels: their own launch cannot fill the chip
     static const long long small_px = [] { const char* e = getenv("SSDN_WGRAD_SMALL_PX"); return e ? atoll(e) : 32768ll; }();   // experiment knob, read once
     if ((long long)a->N * a->H * a->W > small_px || a->mblocks > 1) return false;
@@ -828,10 +830,194 @@ int launch_wgrad_multi(const ssdn_wgrad_args* const* items, int n, hipStream_t s
     return 0;
 }
 
+// ---- thin-K weight gradient: 1..3 real input channels under a 3x3 window ---------------------------------------------------------
+// encode_block_1.0 and the image half of decode_block_1.0 see a 3-channel input in 16 / 32 channel slots: k_wgrad pays 9 column
+// tiles of 32 (30 MFMAs per 16 pixels) and, above all, its row-item staging of the 96-channel gradient for 2.7 GFLOP of real
+// work (78 + 55 us in situ).  Here the GEMM is im2col-shaped: D[m][n] += dz^T[m][pixel] * B[pixel][n] with n = 3 * tap + channel
+// (27 columns) + the bias column of ones -- ONE column tile.  A workgroup walks 16x16 tiles: the gradient tile and the 18x18
+// halo of the first 8 input slots are prefetched into registers during the previous tile's MFMAs and staged in LDS (gradient
+// pixel stride == 64 mod 128 bytes for the transpose reads, input converted to bf16); a wave takes the tile rows wave, wave+4,
+// ...: per row one A fragment per 32 gradient channels (ds_read_b64_tr_b16, as k_wgrad), one B fragment gathered from the halo
+// (8 x ds_read_u16 at this lane's (tap, channel)), MT MFMAs.  The four waves' partial sums meet in LDS in a fixed order; the slab
+// has k_wgrad's layout, so SSDN_OP_WREDUCE is unchanged.
+#define WGN_THREADS 256
+template <int MT>
+__global__ __launch_bounds__(WGN_THREADS) void k_wgrad_thin(ssdn_wgrad_args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int DSTR = wg_stride(MT * 64);            // gradient pixel stride in LDS
+    constexpr int DB = 256 * DSTR, XB = 18 * 18 * 16;   // one gradient tile / one halo of 8 channel slots (16 B per pixel)
+    constexpr int NPD = MT * 4;                          // 16-byte gradient pieces per pixel
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i16 = lane & 15, mh = (lane >> 4) & 1;
+    int mny = 0, mnx = 0;
+    for (int t = 0; t < 9; ++t) { mny = a.dy[t] < mny ? a.dy[t] : mny; mnx = a.dx[t] < mnx ? a.dx[t] : mnx; }
+    const int padT = -mny, padL = -mnx;
+    const bool use0 = a.c0 > 0;
+    const h16* xp = (const h16*)(use0 ? a.src0.p : a.src1.p) + (use0 ? a.src0.co : a.src1.co);
+    const int xcs = use0 ? a.src0.cs : a.src1.cs;
+    const unsigned short* dzp = (const unsigned short*)a.dz.p + a.dz.co;
+    const int tiles_x = a.W >> 4, tiles_y = a.H >> 4;
+    const int ntiles = a.N * tiles_x * tiles_y;
+    const int mpieces = a.M >> 3;                        // real 16-byte pieces per gradient pixel (<= NPD)
+
+    // this lane's B column: n = l31 -> (tap, channel) | bias | nothing
+    const int ncol = 9 * a.kreal;
+    const int bt = l31 < ncol ? l31 / a.kreal : 0, bc = l31 < ncol ? l31 - bt * a.kreal : 0;
+    const int bmode = l31 < ncol ? 0 : (l31 == ncol ? 1 : 2);
+    const int boff = ((a.dy[bt] + padT) * 18 + a.dx[bt] + padL + kh * 8) * 16 + bc * 2;     // + row * 18 * 16 per K-step
+
+    // A fragment lane part (k_wgrad: dlane / abase / read_a1)
+    const int dlane0 = (kh * 8 + (i16 >> 2)) * DSTR + (i16 & 3) * 8 + mh * 32;
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+    half8 pd[NPD], px[2];
+    auto origin = [&](int tile, int& n, int& y0, int& x0) __attribute__((always_inline)) {
+        const int tx = tile % tiles_x; tile /= tiles_x;
+        const int ty = tile % tiles_y;
+        n = tile / tiles_y; y0 = ty << 4; x0 = tx << 4;
+    };
+    auto fetch = [&](int tile) __attribute__((always_inline)) {
+        int n, y0, x0;
+        origin(tile, n, y0, x0);
+#pragma unroll
+        for (int u = 0; u < NPD; ++u) {
+            const int f = tid + u * WGN_THREADS;
+            const int q = f / NPD, cc = f - q * NPD;
+            pd[u] = zero_h8();
+            if (cc < mpieces)
+                pd[u] = __builtin_bit_cast(half8, ld_b8(dzp + ((long long)(n * a.H + y0 + (q >> 4)) * a.W + x0 + (q & 15)) * a.dz.cs + cc * 8));
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int hp = tid + u * WGN_THREADS;
+            const int hy = hp / 18, hx = hp - hy * 18;
+            const int y = y0 - padT + hy, xx = x0 - padL + hx;
+            px[u] = zero_h8();
+            if (hp < 324 && (unsigned)y < (unsigned)a.H && (unsigned)xx < (unsigned)a.W)
+                px[u] = ld_h8(xp + ((long long)(n * a.H + y) * a.W + xx) * xcs);
+        }
+    };
+    auto stage = [&](int buf) __attribute__((always_inline)) {
+        char* dt = smem + buf * (DB + XB);
+        char* xt = dt + DB;
+#pragma unroll
+        for (int u = 0; u < NPD; ++u) {
+            const int f = tid + u * WGN_THREADS;
+            const int q = f / NPD, cc = f - q * NPD;
+            *reinterpret_cast<half8*>(dt + q * DSTR + cc * 16) = pd[u];
+        }
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int hp = tid + u * WGN_THREADS;
+            if (hp < 324) *reinterpret_cast<half8*>(xt + hp * 16) = cvt_h8_to_bf8(px[u]);
+        }
+    };
+
+    int it = 0;
+    const int t0 = blockIdx.x;
+    if (t0 < ntiles) { fetch(t0); stage(0); }
+    __syncthreads();
+    for (int tile = t0; tile < ntiles; tile += gridDim.x, ++it) {
+        const int nxt = tile + gridDim.x;
+        if (nxt < ntiles) fetch(nxt);                       // in flight during this tile's MFMAs
+        const char* dt = smem + (it & 1) * (DB + XB);
+        const char* xt = dt + DB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = wave + 4 * j;                    // tile row = K-step of 16 pixels
+            const char* ab = dt + (row << 4) * DSTR + dlane0;
+            half8 af[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) af[mt] = cat8(tr16(ab + mt * 64), tr16(ab + 4 * DSTR + mt * 64));
+            const char* bp = xt + row * (18 * 16) + boff;
+            u16x8 bv;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) bv[q] = *reinterpret_cast<const unsigned short*>(bp + q * 16);
+            if (bmode != 0) {
+#pragma unroll
+                for (int q = 0; q < 8; ++q) bv[q] = bmode == 1 ? (unsigned short)0x3f80 : (unsigned short)0;
+            }
+            const half8 bfrag = __builtin_bit_cast(half8, bv);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, af[mt]), __builtin_bit_cast(bf16x8, bfrag), acc[mt], 0, 0, 0);
+        }
+        __syncthreads();                                     // every wave is done with buffer it & 1 ... and with (it+1) & 1 long ago
+        if (nxt < ntiles) stage((it + 1) & 1);
+        __syncthreads();
+    }
+    // ---- the four waves' partial sums, in wave order ----
+    float* red = reinterpret_cast<float*>(smem);            // [wave][mt][r][lane]
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[((wave * MT + mt) * 16 + r) * 64 + lane] = acc[mt][r];
+    __syncthreads();
+    float* slab = a.slab + (long long)blockIdx.x * 9 * a.Mpad * a.Kpad;
+    for (int o = tid; o < MT * 16 * 64; o += WGN_THREADS) {
+        const int ln = o & 63, r = (o >> 6) & 15, mt = o >> 10;
+        float sum = 0.f;
+#pragma unroll
+        for (int w4 = 0; w4 < 4; ++w4) sum += red[((w4 * MT + mt) * 16 + r) * 64 + ln];
+        const int n = ln & 31, m = mt * 32 + 8 * (r >> 2) + 4 * (ln >> 5) + (r & 3);        // D col = lane & 31, D row as k_wgrad
+        if (m >= a.Mpad) continue;
+        if (n < ncol) {
+            const int t = n / a.kreal, c = n - t * a.kreal;
+            slab[((long long)t * a.Mpad + m) * a.Kpad + c] = sum;
+        } else if (n == ncol) {
+            a.bslab[(long long)blockIdx.x * a.Mpad + m] = sum;
+        }
+    }
+}
+static bool wgrad_thin_ok(const ssdn_wgrad_args* a) {
+    static const bool off = getenv("SSDN_NO_THIN_WGRAD") != nullptr;      // A/B aid, read once
+    if (off || a->kreal < 1 || a->kreal > 3 || a->ntaps != 9 || a->csplit > 1 || a->mblocks > 1) return false;
+    if ((a->H & 15) || (a->W & 15) || (a->M & 7) || a->Mpad > 96 || a->Kpad < a->kreal) return false;
+    if (a->c0 > 0 ? (a->up0 || a->c1 > 0) : a->c1 <= 0) return false;
+    const ssdn_view& v = a->c0 > 0 ? a->src0 : a->src1;
+    if ((v.cs & 7) || (v.co & 7) || (a->dz.cs & 7) || (a->dz.co & 7)) return false;
+    int mny = 0, mxy = 0, mnx = 0, mxx = 0;
+    for (int t = 0; t < 9; ++t) {
+        if (a->coff[t] != 0) return false;
+        mny = a->dy[t] < mny ? a->dy[t] : mny; mxy = a->dy[t] > mxy ? a->dy[t] : mxy;
+        mnx = a->dx[t] < mnx ? a->dx[t] : mnx; mxx = a->dx[t] > mxx ? a->dx[t] : mxx;
+    }
+    return mxy - mny == 2 && mxx - mnx == 2;                 // a 3x3 window: the halo is 18 x 18
+}
+template <int MT>
+static int wgrad_thin_launch(const ssdn_wgrad_args* a, hipStream_t s) {
+    const size_t lds = 2 * ((size_t)256 * wg_stride(MT * 64) + 18 * 18 * 16);
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad_thin<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const double px = (double)a->N * a->H * a->W;
+    prof_begin(SSDN_PROF_WGRAD, s);
+    hipLaunchKernelGGL(k_wgrad_thin<MT>, dim3(a->nslabs), dim3(WGN_THREADS), lds, s, *a);
+    prof_end(SSDN_PROF_WGRAD, s, 2.0 * px * a->M * a->kreal * 9, px * 2.0 * (a->M + a->kreal));
+    SSDN_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+static int launch_wgrad_thin(const ssdn_wgrad_args* a, hipStream_t s) {
+    switch (a->Mpad / 32) {
+        case 1: return wgrad_thin_launch<1>(a, s);
+        case 2: return wgrad_thin_launch<2>(a, s);
+        default: return wgrad_thin_launch<3>(a, s);
+    }
+}
+
 int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     WgPrep prep;
     int rc = wgrad_prepare(a, &prep);
     if (rc) return rc;
+    if (wgrad_thin_ok(a)) return launch_wgrad_thin(a, s);
     const WgGeom& g = prep.g;
     const WgAux& x = prep.x;
     const WgItems& wi = prep.wi;

@@ -250,6 +250,7 @@ class DeviceNet:
             s.ltw, s.lth, s.ltn = a["ltw"], a["lth"], a["ltn"]
             s.csplit = a.get("csplit", 0)
             s.mblocks = a.get("mblocks", 1)
+            s.kreal = a.get("kreal", 0)
             if L.load().ssdn_wgrad_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("wgrad %s: %s" % (a["layer"], L.load().ssdn_last_error().decode()))
             return op.type, s

@@ -399,7 +399,8 @@ class NetPlan:
         bslab = self.T("bslab%d" % self.nwgrad, "f32", (mblocks * nslabs * Mpad,))
         self.bwd.append(Op("wgrad", dict(layer=layer.name, dz=dz, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                          taps=list(taps), coff=coff, M=Mz, Mpad=Mpad, Ktot=Ktot, Kpad=Kpad, nslabs=nslabs,
-                                         ltw=ltw, lth=lth, ltn=ltn, csplit=csplit, mblocks=mblocks, slab=slab, bslab=bslab)))
+                                         ltw=ltw, lth=lth, ltn=ltn, csplit=csplit, mblocks=mblocks, slab=slab, bslab=bslab,
+                                         kreal=int(cin_real) if cblocks is None else 0)))
         for mb in range(mblocks):
             mo = m_off + mb * Mz
             M_real = min(Mz, layer.M - mo)

@@ -58,7 +58,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("dz", View), ("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32),
                 ("H", i32), ("W", i32), ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("coff", i32 * MAX_TAPS),
                 ("M", i32), ("Mpad", i32), ("Ktot", i32), ("Kpad", i32), ("slab", vp), ("bslab", vp), ("nslabs", i32), ("ltw", i32),
-                ("lth", i32), ("ltn", i32), ("csplit", i32), ("mblocks", i32)]
+                ("lth", i32), ("ltn", i32), ("csplit", i32), ("mblocks", i32), ("kreal", i32)]
 
 
 class WreduceArgs(C.Structure):
