@@ -312,7 +312,7 @@ class DenoiserEngine:
         self.noise_param = torch.zeros((B,), **f32)
         self.coords = torch.zeros((ncoords, 2), dtype=torch.int64, device=device)
         self.ncoords = ncoords
-        self.nchunks = max(1, min(64, (H * W) // 256))      # B x nchunks workgroups: >= 2 per CU at BASELINE sizes
+        self.nchunks = max(1, min(64, (H * W) // 1024))     # (B x HW/256 workgroups measured slower: 33 vs 20 us)
         self.partial = torch.zeros((B, self.nchunks, 2), **f32)
         self.est_raw = torch.zeros((B,), **f32)
         self.g_est_var = torch.zeros((B,), **f32)
