@@ -1,0 +1,108 @@
+"""GPU: `Denoiser.train_step` with world_size 2 -- two processes SHARING the one GPU of the test box, torch.distributed backend
+"gloo" on device tensors (RCCL needs one GPU per rank; the exchange code path -- bucket events recorded inside the backward
+list, per-bucket asynchronous all-reduce on the communication stream behind those events, Adam waiting for the collectives and
+folding in 1 / world -- is the one `bench.py --gpus N` runs on RCCL).  After two optimisation steps on the two halves of a
+minibatch both ranks must hold the SAME weights, and those must equal a single-process run on the whole minibatch up to fp32
+summation order (reference semantics: mean over the GLOBAL batch, train.py:201 under nn.DataParallel)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _inputs(B, P):
+    import restate as R
+    clean = R.hash_tensor((B, 3, P, P), 301, 0, 1)
+    noisy = torch.clamp(clean + R.hash_tensor((B, 3, P, P), 302, -1, 1) * 0.17, 0, 1)
+    return clean, noisy
+
+
+def _make(seed=11):
+    import ssdn
+    from ssdn.denoiser import Denoiser
+    from ssdn.params import ConfigValue, NoiseAlgorithm, NoiseValue
+    cfg = ssdn.cfg.base()
+    cfg[ConfigValue.ALGORITHM] = NoiseAlgorithm.SELFSUPERVISED_DENOISING
+    cfg[ConfigValue.NOISE_STYLE] = "gauss25"
+    cfg[ConfigValue.NOISE_VALUE] = NoiseValue.KNOWN
+    ssdn.cfg.infer(cfg, model_only=True)
+    torch.manual_seed(seed)
+    return Denoiser(cfg, device="cuda:0")
+
+
+def _steps(d, noisy, clean, exchange, nsteps=2):
+    from ssdn.datasets import NoisyDataset
+    MD = NoisyDataset.Metadata
+    B = noisy.shape[0]
+    npar = torch.full((B, 1, 1, 1), 25 / 255.0)
+    d.train()
+    for _ in range(nsteps):
+        d.train_step([noisy, None, {MD.INPUT_NOISE_VALUES: npar, MD.CLEAN: clean}], 3e-4, exchange)
+    torch.cuda.synchronize()
+    return d.flat.detach().cpu().numpy().copy()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch.distributed as dist
+    from ssdn.hip import dp
+    r, w, _ = dp.init_from_env("gloo")
+    d = _make()
+    B, P = 4, 32
+    clean, noisy = _inputs(B, P)
+    lo, hi = dp.shard_rows(B, r, w)
+    ex = d.gradient_exchange(w)
+    assert ex.overlapped and len(ex.ranges) >= 3          # events + communication stream, as with RCCL
+    flat = _steps(d, noisy[lo:hi], clean[lo:hi], ex)
+    q.put((rank, flat))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_train_step_equals_single_process():
+    import queue
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    try:
+        for _ in range(2):
+            r, flat = q.get(timeout=300)
+            got[r] = flat
+    except queue.Empty:          # pragma: no cover
+        pass
+    for p in procs:
+        p.join(timeout=120)
+        if p.is_alive():
+            p.kill()
+    assert sorted(got) == [0, 1] and all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert np.array_equal(got[0], got[1]), "the ranks diverged"
+    d = _make()
+    clean, noisy = _inputs(4, 32)
+    want = _steps(d, noisy, clean, None)
+    n = d._n_main
+    p0 = _make().flat.detach().cpu().numpy()[:n]
+    upd_w, upd_g = want[:n] - p0, got[0][:n] - p0
+    # Adam's first steps move every weight by ~lr regardless of the gradient's size, so compare the UPDATES: identical per-sample
+    # gradients, summed per shard then across ranks instead of over the whole batch (fp32 rounding only)
+    cos = float((upd_w * upd_g).sum() / (np.linalg.norm(upd_w) * np.linalg.norm(upd_g) + 1e-30))
+    assert cos >= 0.999, cos
+    # (a weight whose gradient is ~0 may step the other way after a last-bit difference: Adam's first steps are sign-like)
+    frac_off = float(np.mean(np.abs(upd_w - upd_g) > 0.5 * 3e-4))
+    assert frac_off <= 0.01, frac_off
