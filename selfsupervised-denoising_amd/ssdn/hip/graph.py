@@ -378,6 +378,11 @@ class NetPlan:
         default_groups = list(groups)
         if small and small_g > 0:
             groups = [small_g]
+        elif mblocks == 1 and cblocks is None and N * H * W <= int(os.environ.get("SSDN_MID_WGRAD_PX", "131072")) and \
+                int(os.environ.get("SSDN_MID_WGRAD_G", "2")) > 0:
+            # the 32x32 stage: two column groups on half the partitions -- the cycle model (which prices a launch alone on
+            # the chip) prefers one group; in situ half the slab traffic wins (-45 us per step, measured)
+            groups = [int(os.environ.get("SSDN_MID_WGRAD_G", "2"))]
         for attempt in (groups, default_groups):
             for G in attempt:
                 if G > 1 and 4 * -(-ctiles // (4 * G)) * (G - 1) >= ctiles:
