@@ -21,7 +21,8 @@ def family(k):
     if not m: return None
     name, t = m.group(1), m.group(2) or ""
     if name == "k_cdma": return "k_cdma<3,*>" if t.startswith("<3") else "k_cdma<2|1,*>"
-    if name in ("k_conv", "k_gdma", "k_wgrad", "k_wgrad_multi"): return name
+    if name in ("k_conv", "k_gdma", "k_wgrad_multi"): return name
+    if name.startswith("k_wgrad"): return "k_wgrad"            # k_wgrad<...>, k_wgrad_thin<MT>
     if name.startswith("k_wreduce"): return "k_wreduce*"
     return "elementwise/head/adam"
 res = {}
