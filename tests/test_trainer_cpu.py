@@ -140,3 +140,30 @@ def test_cli_surface(tmp_path):
         args = vars(parser.parse_args(["train", "start", "-a", "ssdn", "-n", "gauss25", "-t", "x", "-i", "1"]))
         args["PARSER"] = parser
         cmds["train"].execute(args)
+
+
+def test_native_tensorboard_event_file(tmp_path):
+    """N4: the trainer's scalars also go to a TensorBoard event file written without the tensorboard package: TFRecord framing with
+    masked CRC-32C, Event { wall_time, step, file_version | summary { value { tag, simple_value } } }."""
+    import struct
+    from ssdn import logging_helper as lh
+    assert lh.crc32c(b"123456789") == 0xE3069283                      # the CRC-32C check value
+    w = lh.ScalarWriter(str(tmp_path))
+    w.add_scalar("train/loss", 1.5, 64)
+    w.add_scalar("valid/psnr_out", 31.25, 128)
+    w.close()
+    files = [f for f in os.listdir(tmp_path) if f.startswith("events.out.tfevents.")]
+    assert len(files) == 1
+    raw = open(os.path.join(tmp_path, files[0]), "rb").read()
+    recs, pos = [], 0
+    while pos < len(raw):
+        (n,) = struct.unpack_from("<Q", raw, pos)
+        assert struct.unpack_from("<I", raw, pos + 8)[0] == lh._masked_crc(raw[pos:pos + 8])
+        data = raw[pos + 12:pos + 12 + n]
+        assert struct.unpack_from("<I", raw, pos + 12 + n)[0] == lh._masked_crc(data)
+        recs.append(data)
+        pos += 16 + n
+    assert len(recs) == 3 and b"brain.Event:2" in recs[0]
+    assert recs[1][0] == 0x09 and b"train/loss" in recs[1] and struct.pack("<f", 1.5) in recs[1] and recs[1][9:11] == b"\x10\x40"
+    assert b"valid/psnr_out" in recs[2] and struct.pack("<f", 31.25) in recs[2] and recs[2][9:12] == b"\x10\x80\x01"
+    assert open(os.path.join(tmp_path, "scalars.csv")).read().count("\n") == 3
