@@ -254,3 +254,19 @@ def test_device_patch_stream_matches_the_host_pipeline(alg, style):
         # every manipulated pixel took its value from the reference's window around it ([0, c + r] clipped, not the pixel itself)
         noisy_ref = dev[1]                                                 # (independent noise: only the geometry is checked)
         assert int(c.min()) >= 0 and int(c[..., 0].max()) < 32 and int(c[..., 1].max()) < 32
+
+
+def test_h5lite_reads_a_libhdf5_written_file(golden_dir):
+    """Pins the dependency-free reader against the REAL library: tests/golden/g_libhdf5_dataset.h5 was written by libhdf5 1.10
+    (oracle/h5gen/make_fixture.c, the layout of the reference's external/dataset_tool_h5.py:104-111: /shapes int32 [N,3],
+    /images vlen<uint8> [N], one element per write like h5py's dset[idx] = ...)."""
+    f = h5lite.ImageFile(os.path.join(golden_dir, "g_libhdf5_dataset.h5"))
+    hs, ws = [9, 12, 7, 16, 33], [17, 8, 7, 24, 5]
+    assert len(f) == 5
+    for i in range(5):
+        k = np.arange(3 * hs[i] * ws[i])
+        want = ((i * 131 + k * 7 + (k >> 8)) & 255).astype(np.uint8).reshape(3, hs[i], ws[i])
+        img = f.image(i)
+        assert img.dtype == np.uint8 and np.array_equal(img, want)
+    ds = HDF5Dataset(os.path.join(golden_dir, "g_libhdf5_dataset.h5"), channels=3)
+    assert len(ds) == 5 and tuple(ds[3][0].shape) == (3, 24, 16)          # (the reference's H/W swap, reproduced)
