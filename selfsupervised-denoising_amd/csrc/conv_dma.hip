@@ -31,6 +31,17 @@
 #include "common.h"
 #include <cstdlib>
 
+// Tuning aids (ablation bits, phase stamps, weight replication) are compiled in only with -DSSDN_CDMA_TUNING (tools/cdma_probe.sh
+// builds that way): as run-time flags they cost ~40 scalar instructions and 10 branches PER STEP of a kernel that is
+// instruction-issue bound (two waves per SIMD, ~300 instructions per 18 MFMAs).
+#ifdef SSDN_CDMA_TUNING
+#define CD_ABL(xx, bit) (((xx).ablate & (bit)) != 0)
+#define CD_TUNING 1
+#else
+#define CD_ABL(xx, bit) false
+#define CD_TUNING 0
+#endif
+
 namespace {
 
 constexpr int CD_TBYTES = 31744;   // 18 x 18 pixels x 96 B = 31104, + 640 B that hold the bias (see below)
@@ -181,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // ---- buffer resources ---------------------------------------------------------------------------------------------------
     // (num_records = 2 GiB for every resource: all tensors are smaller -- checked by the launcher -- and the one out-of-range
     //  offset used, 0x80000000, still reads as zero; constants cost no live SGPRs)
-    const unsigned long long wp = (unsigned long long)a.w + (x.wrep > 1 ? (unsigned long long)((blockIdx.x >> 3) % x.wrep) * (9ull * a.Mpad * a.Ktot * 2) : 0ull);
+    const unsigned long long wp = (unsigned long long)a.w + ((CD_TUNING && x.wrep > 1) ? (unsigned long long)((blockIdx.x >> 3) % x.wrep) * (9ull * a.Mpad * a.Ktot * 2) : 0ull);
     const u32x4_t rs_w = {(unsigned)wp, (unsigned)(wp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
     const unsigned long long wcp = (unsigned long long)a.wc;
     const u32x4_t rs_wc = {(unsigned)wcp, (unsigned)(wcp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
@@ -193,11 +204,11 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
 
     int tr_i = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
-        if (x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
+        if (CD_TUNING && x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
     };
     // waves 0-1: DMA of the weight slice (chunk c, halo tap tseq = 3i+j) into weight buffer `wpar`
     auto issue_w = [&](int c, int tseq, int wpar) __attribute__((always_inline)) {
-        if (x.ablate & 2) return;
+        if (CD_ABL(x, 2)) return;
         const int tw = x.rev ? 8 - tseq : tseq;
         const unsigned dst = wlds0 + wpar * WBYTES;
         if (a.wc) {
@@ -215,8 +226,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
 #pragma unroll
             for (int u = 0; u < NWU; ++u)
                 if (lw + 2 * u < NWQ) {
-                    if (x.ablate & 128) { if (lane > 64) dma16(dst + (lw + 2 * u) * 1024, wv48[u], rs_w, soff); }
-                    else dma16(dst + (lw + 2 * u) * 1024, (x.ablate & 64) ? (int)0x80000000 : wv48[u], rs_w, soff);
+                    if (CD_ABL(x, 128)) { if (lane > 64) dma16(dst + (lw + 2 * u) * 1024, wv48[u], rs_w, soff); }
+                    else dma16(dst + (lw + 2 * u) * 1024, CD_ABL(x, 64) ? (int)0x80000000 : wv48[u], rs_w, soff);
                 }
         } else {
 #pragma unroll
@@ -249,7 +260,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         return ok ? (xs * cs + (cc ^ pr) * 8) * 2 : (int)0x80000000;
     };
     auto issue_rows = [&](const CdTile& t, int c, int tpar, int rlE, int rlO, int u0, int nu) __attribute__((always_inline)) {
-        if (x.ablate & 4) return;
+        if (CD_ABL(x, 4)) return;
         const int k0 = c * 48;
         const bool from0 = k0 < a.c0;
         const bool up = from0 && a.up0;
@@ -273,8 +284,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             const int soff = __builtin_amdgcn_readfirstlane(rowok ? (((t.n * Hs + ys) * Ws) * cs + cbase) * 2 : 0);      // wave-uniform
             const int voff = rowok ? ((hy & 1) ? rlO : rlE) : (int)0x80000000;
             const unsigned ldsrow = dst + hy * (full ? 1728 : 576) + half * 864;
-            if (x.ablate & 128) { if (lane > 64) dma16(ldsrow, voff, rs, soff); }
-            else if (act) dma16(ldsrow, (x.ablate & 64) ? (int)0x80000000 : voff, rs, soff);
+            if (CD_ABL(x, 128)) { if (lane > 64) dma16(ldsrow, voff, rs, soff); }
+            else if (act) dma16(ldsrow, CD_ABL(x, 64) ? (int)0x80000000 : voff, rs, soff);
         }
     };
 
@@ -353,8 +364,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             };
             // step tail: own DMA landed, then ONE barrier: every wave's DMA landed and every wave is done with this step's buffers
             auto step_tail = [&](int t) __attribute__((always_inline)) {
-                if ((wload || t == 8) && !(x.ablate & 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!(x.ablate & 32)) __builtin_amdgcn_s_barrier();
+                if ((wload || t == 8) && !CD_ABL(x, 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (!CD_ABL(x, 32)) __builtin_amdgcn_s_barrier();
                 wpar ^= 1;
             };
             if (c < x.nfull) {
@@ -368,15 +379,15 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         lds_wait0<MT>(aq0, bq0);                                            \
         cd_reads<MT, 3, I, J, 1>(aq1, bq1, ap, bp);                         \
         __builtin_amdgcn_sched_barrier(0);                                  \
-        if (!(x.ablate & 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
+        if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
         __builtin_amdgcn_sched_barrier(0);                                  \
         lds_wait0<MT>(aq1, bq1);                                            \
         cd_reads<MT, 3, I, J, 2>(aq0, bq0, ap, bp);                         \
         __builtin_amdgcn_sched_barrier(0);                                  \
-        if (!(x.ablate & 1)) cd_mmas<MT, BF>(acc, aq1, bq1);                \
+        if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, aq1, bq1);                \
         __builtin_amdgcn_sched_barrier(0);                                  \
         lds_wait0<MT>(aq0, bq0);                                            \
-        if (!(x.ablate & 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
+        if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
         __builtin_amdgcn_sched_barrier(0);                                  \
         step_tail(T);                                                       \
     }
@@ -407,7 +418,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         }
 
         // ---- epilogue: the tile buffer of the last chunk (tpar ^ 1 now) is dead; the other one holds / receives the next tile ----
-        if (!(x.ablate & 8)) {
+        if (!CD_ABL(x, 8)) {
             char* reg = tbuf0 + (tpar ^ 1) * CD_TBYTES + w * (32 * OSTR);
             const int pix_t = (cur.n * a.H + cur.y0 + 4 * w) * a.W + cur.x0;     // first pixel of this wave's 4 rows
 #pragma unroll
