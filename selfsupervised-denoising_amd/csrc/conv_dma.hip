@@ -160,24 +160,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // A fragments (weights): lane = row l31 (+32 mt), k half kh
     const int asw = (kh ^ ((l31 >> 3) & 1)) << 4;
     const int aB48 = l31 * 96 + asw, aB16 = l31 * 32 + asw;
-    // weight DMA (waves 0-1): instruction q = lw + 2u covers pieces [64q, 64q+64) of the slice; piece Pw = 6 m + (c ^ ((m >> 3) & 1))
-    // -> byte offset of (row m, piece c) inside the [Mpad][Ktot] tap slice
-    constexpr int NWU = (NWQ + 1) / 2;
-    int wv48[NWU];
-#pragma unroll
-    for (int u = 0; u < NWU; ++u) {
-        const int Pw = (lw + 2 * u) * 64 + lane;
-        const int m = Pw / 6, c = (Pw - m * 6) ^ ((m >> 3) & 1);
-        wv48[u] = (m * a.Ktot + c * 8) * 2;
-    }
-    constexpr int NWU16 = (MT + 1) / 2;      // 16-channel slice: [MT*32][2 pieces] = MT instructions
-    int wv16[NWU16];
-#pragma unroll
-    for (int u = 0; u < NWU16; ++u) {
-        const int Pw = (lw + 2 * u) * 64 + lane;
-        const int m = Pw >> 1, c = (Pw & 1) ^ ((m >> 3) & 1);
-        wv16[u] = (m * a.Ktot + c * 8) * 2;
-    }
+    constexpr int NWU = (NWQ + 1) / 2;       // weight DMA instructions per wave per slice (waves 0-1, q = lw + 2u)
     // epilogue: row instruction k covers 16-byte pieces [64k, 64k+64) of this wave's 32-pixel pass; piece p = (pixel p / cpp,
     // piece p % cpp); pixel px = (row px >> 4 of the pass, column px & 15)
     const int cpp = x.m_cnt >> 3;
@@ -192,8 +175,6 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // ---- buffer resources ---------------------------------------------------------------------------------------------------
     // (num_records = 2 GiB for every resource: all tensors are smaller -- checked by the launcher -- and the one out-of-range
     //  offset used, 0x80000000, still reads as zero; constants cost no live SGPRs)
-    const unsigned long long wp = (unsigned long long)a.w + ((CD_TUNING && x.wrep > 1) ? (unsigned long long)((blockIdx.x >> 3) % x.wrep) * (9ull * a.Mpad * a.Ktot * 2) : 0ull);
-    const u32x4_t rs_w = {(unsigned)wp, (unsigned)(wp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
     const unsigned long long wcp = (unsigned long long)a.wc;
     const u32x4_t rs_wc = {(unsigned)wcp, (unsigned)(wcp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
@@ -211,29 +192,14 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         if (CD_ABL(x, 2)) return;
         const int tw = x.rev ? 8 - tseq : tseq;
         const unsigned dst = wlds0 + wpar * WBYTES;
-        if (a.wc) {
-            // chunk-major pre-swizzled copy [tap][chunk][Mpad][kc]: the slice IS the LDS image -> linear 1 KiB pieces
-            const bool full = c < x.nfull;
-            const int sbase = ((tw * a.Mpad * a.Ktot) + c * 48 * a.Mpad + x.m_base * (full ? 48 : 16)) * 2;
-            const int nq = full ? NWQ : MT;
+        // chunk-major pre-swizzled copy [tap][chunk][Mpad][kc] (ssdn_conv_args.wc, mandatory for this kernel): the slice IS the
+        // LDS image -> linear 1 KiB pieces
+        const bool full = c < x.nfull;
+        const int sbase = ((tw * a.Mpad * a.Ktot) + c * 48 * a.Mpad + x.m_base * (full ? 48 : 16)) * 2;
+        const int nq = full ? NWQ : MT;
 #pragma unroll
-            for (int u = 0; u < NWU; ++u)
-                if (lw + 2 * u < nq) dma16(dst + (lw + 2 * u) * 1024, lane * 16, rs_wc, sbase + (lw + 2 * u) * 1024);
-            return;
-        }
-        const int soff = ((tw * a.Mpad + x.m_base) * a.Ktot + c * 48) * 2;
-        if (c < x.nfull) {
-#pragma unroll
-            for (int u = 0; u < NWU; ++u)
-                if (lw + 2 * u < NWQ) {
-                    if (CD_ABL(x, 128)) { if (lane > 64) dma16(dst + (lw + 2 * u) * 1024, wv48[u], rs_w, soff); }
-                    else dma16(dst + (lw + 2 * u) * 1024, CD_ABL(x, 64) ? (int)0x80000000 : wv48[u], rs_w, soff);
-                }
-        } else {
-#pragma unroll
-            for (int u = 0; u < NWU16; ++u)
-                if (lw + 2 * u < MT) dma16(dst + (lw + 2 * u) * 1024, wv16[u], rs_w, soff);
-        }
+        for (int u = 0; u < NWU; ++u)
+            if (lw + 2 * u < nq) dma16(dst + (lw + 2 * u) * 1024, lane * 16, rs_wc, sbase + (lw + 2 * u) * 1024);
     };
     // waves 2-3: DMA of halo-tile ROWS.  A row of a 48-channel chunk is 18 pixels x 6 pieces = 108 pieces = two instructions of
     // 54 active lanes (the other 10 are EXEC-masked: masked lanes write nothing); a row of the 16-channel chunk is 36 pieces =
@@ -272,16 +238,21 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         const unsigned dst = tlds0 + tpar * CD_TBYTES;
         const bool full = c < x.nfull;
         const bool act = full ? lane < 54 : lane < 36;
+        // everything about a row is scalar: byte offset of source row ys = rbase + ys * rstride (kept on the scalar unit:
+        // the inputs are made SGPR values here, so the compiler does not route the address through VALU + readfirstlane)
+        const int rstride = __builtin_amdgcn_readfirstlane(Ws * cs * 2);
+        const int rbase = __builtin_amdgcn_readfirstlane((t.n * Hs * Ws * cs + cbase) * 2);
+        const int ybs = __builtin_amdgcn_readfirstlane(yb);
+        const int ush = up ? 1 : 0;
 #pragma unroll
         for (int uu = 0; uu < 18; ++uu) {
             if (uu >= nu) break;               // (nu is a constant at every call site: the loop unrolls to nu items)
             const int r = lw + 2 * (u0 + uu);
             const int hy = full ? r >> 1 : r, half = full ? r & 1 : 0;
             if (hy >= 18) continue;
-            const int y = yb + hy;
+            const int y = ybs + hy;
             const bool rowok = (unsigned)y < (unsigned)a.H;
-            const int ys = up ? y >> 1 : y;
-            const int soff = __builtin_amdgcn_readfirstlane(rowok ? (((t.n * Hs + ys) * Ws) * cs + cbase) * 2 : 0);      // wave-uniform
+            const int soff = rbase + (y >> ush) * rstride;                    // (an out-of-image row fetches nothing: voff is out of range)
             const int voff = rowok ? ((hy & 1) ? rlO : rlE) : (int)0x80000000;
             const unsigned ldsrow = dst + hy * (full ? 1728 : 576) + half * 864;
             if (CD_ABL(x, 128)) { if (lane > 64) dma16(ldsrow, voff, rs, soff); }
@@ -564,7 +535,7 @@ static bool cd_window(const ssdn_conv_args* a, int* padT, int* padL, int* rev) {
 bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size) {
     int pt, pl, rv;
     if (!cd_window(a, &pt, &pl, &rv)) return false;
-    if (a->dst32 || (a->H & 15) || (a->W & 15)) return false;
+    if (a->dst32 || (a->H & 15) || (a->W & 15) || !a->wc) return false;       // (wc: the chunk-major weight copy this kernel streams)
     const int tail = a->Ktot % 48;
     if (tail != 0 && tail != 16) return false;
     if (a->c0 % 48 && a->c0 != a->Ktot) return false;           // a chunk never straddles the two sources
