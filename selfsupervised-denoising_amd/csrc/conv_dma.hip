@@ -31,10 +31,10 @@
 #include "common.h"
 #include <cstdlib>
 
-// Tuning aids (ablation bits, phase stamps, weight replication) are compiled in only with -DSSDN_CDMA_TUNING (tools/cdma_probe.sh
-// builds that way): as run-time flags they cost ~40 scalar instructions and 10 branches PER STEP of a kernel that is
+// Tuning aids (ablation bits, phase stamps, weight replication) are compiled in only with -DSSDN_TUNING (`make TUNING=1`; tools/cdma_probe.sh
+// and the trace mode of tools/conv_bench.py need such a build): as run-time flags they cost ~40 scalar instructions and 10 branches PER STEP of a kernel that is
 // instruction-issue bound (two waves per SIMD, ~300 instructions per 18 MFMAs).
-#ifdef SSDN_CDMA_TUNING
+#if defined(SSDN_CDMA_TUNING) || defined(SSDN_TUNING)
 #define CD_ABL(xx, bit) (((xx).ablate & (bit)) != 0)
 #define CD_TUNING 1
 #else

@@ -19,6 +19,15 @@
 // arithmetic -- which is what this structure removes.
 // Epilogue: bias (+LeakyReLU) in registers, tile transposed through LDS, 16-byte pixel-contiguous stores.
 #include "common.h"
+// tuning aids (ablation bits, s_memtime stamps, start-up desynchronisation) exist only in -DSSDN_TUNING builds: as run-time flags
+// they are instructions and branches in kernels that are bound by exactly those
+#ifdef SSDN_TUNING
+#define CV_ABL(xx, bit) (((xx).ablate & (bit)) != 0)
+#define CV_TUNING 1
+#else
+#define CV_ABL(xx, bit) false
+#define CV_TUNING 0
+#endif
 #include <cstdlib>
 
 
@@ -123,7 +132,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     // no registers, no ds_write, asynchronous) into the second of two UNPADDED tile buffers while chunk c is on the matrix
     // cores -- a 1x1 layer re-stages its tile for every 18 MFMAs per wave, and with synchronous staging that latency was
     // most of its time.  (LDS-DMA writes 64 consecutive 16-byte pieces per wave instruction, hence the unpadded layout.)
-    const bool ASYNC = conv_async(a, KC) && !(x.ablate & 128);
+    const bool ASYNC = conv_async(a, KC) && !CV_ABL(x, 128);
     const int tstr = ASYNC ? KC * 2 : STR;                 // LDS stride of a tile pixel
     const int tbytes = g.NP * tstr;
     char* tile = smem;
@@ -159,7 +168,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
 
     int tr_i = 0;
     auto stamp = [&]() {
-        if (x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
+        if (CV_TUNING && x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
     };
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
     const int nchunks = a.Ktot / KC;
@@ -182,7 +191,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     half8 wrA[NW], wrB[NW], wrC[NW];    // three register sets: the weight stream runs THREE steps ahead of the MFMA work
     // every workgroup walks the taps in a different rotation: all workgroups of a launch stream the SAME 166 KB of weights,
     // and in lock-step they would all hit the same few L2 channels with the same 9 KB slice at the same moment
-    const int rot = ((x.ablate & 64) || x.allw) ? 0 : (int)(wg_tile % (unsigned)a.ntaps);
+    const int rot = (CV_ABL(x, 64) || x.allw) ? 0 : (int)(wg_tile % (unsigned)a.ntaps);
     auto tap_of = [&](int tseq) { int t = tseq + rot; return t >= a.ntaps ? t - a.ntaps : t; };
     auto w_issue = [&](half8 (&wr)[NW], int step) {
         step = step < nsteps ? step : nsteps - 1;      // past the end: re-load the last slice (never committed)
@@ -200,7 +209,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     // ---- halo tile staging: flat index f = tid + 256*j over (halo pixel, 16-B piece); 8 loads in flight per thread ----
     const int nflat = g.NP * CC8;
     auto stage_tile = [&](int ch) {
-        if (x.ablate & 2) return;
+        if (CV_ABL(x, 2)) return;
         for (int f0 = tid; f0 < nflat; f0 += 8 * CONV_THREADS) {
             half8 v[8];
 #pragma unroll
@@ -256,7 +265,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
 
     // ---- one pipeline step on the matrix cores: KS K-steps, fully unrolled, ping-pong fragments, immediate offsets ----
     auto compute = [&](const char* wl, int step) {
-        if (x.ablate & 1) return;
+        if (CV_ABL(x, 1)) return;
         const int ch = fdiv(step, x.mg_ntaps), t = tap_of(step - ch * a.ntaps);
         const int toff = (a.dy[t] * g.HW + a.dx[t]) * tstr;
         const char* tcur = tile + (ASYNC ? (step & 1) * tbytes : 0);
@@ -296,7 +305,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             w_commit(wr_next, buf_next);
         }
         if (ASYNC) async_wait();          // the tile of step+1 has landed (every wave waits for its own loads, then the barrier)
-        if (!(x.ablate & 32)) __syncthreads();
+        if (!CV_ABL(x, 32)) __syncthreads();
         if (ASYNC && step + 2 < nsteps) async_issue(step + 2, step & 1);   // the buffer of `step` is free now
         stamp();
     };
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             __syncthreads();
             stamp();
             if (ch + 1 < nchunks) issue_chunk(ch + 1);
-            if (!(x.ablate & 1)) {
+            if (!CV_ABL(x, 1)) {
                 // the 9 x KS K-steps of the chunk as ONE software pipeline: fragments are read two K-steps ahead, across tap
                 // boundaries (per-tap pipelines exposed an LDS round trip at every tap: ~250 cycles per 2-MFMA K-step)
                 constexpr int S = 9 * KS;
@@ -398,7 +407,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             stamp();
             __syncthreads();
         }
-        if (x.ablate & 16) return;
+        if (CV_ABL(x, 16)) return;
         // ---- flat epilogue: registers -> LDS [pixel][OSTR] -> 16-byte pieces of 256 consecutive pixels ----
         constexpr int OSTRF = MT * 64 + 16;
         char* otf = smem;
@@ -564,7 +573,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     } else {
     // buffers alternate wl0 / wl1 by step parity; register sets rotate A, B, C by step mod 3.
     // invariant at the top of step s: LDS buffer s&1 holds W(s); W(s+1), W(s+2) are in flight in their register sets.
-    if (x.desync && blockIdx.x < 512) {
+    if (CV_TUNING && x.desync && blockIdx.x < 512) {
         const int k = (int)((blockIdx.x * 2654435761u) >> 29) * x.desync;
         for (int i = 0; i < k; ++i) __builtin_amdgcn_s_sleep(127);
     }
@@ -604,7 +613,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     }
     }
 
-    if (x.ablate & 16) return;
+    if (CV_ABL(x, 16)) return;
     // ---- epilogue: D row = 8*(r>>2) + 4*(lane>>5) + (r&3)  (output channel), D col = lane&31 (pixel) -------------
     if (a.dst32) {
         // fp32 NCHW planar output (net_out of the last 1x1 layer: M <= 9 channels): direct stores, coalesced along x
@@ -613,7 +622,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
             const int q = wave * 64 + nt * 32 + l31;
             const int tx = q & (g.TW - 1), ty = (q >> a.ltw) & (g.TH - 1), tn = q >> (a.ltw + a.lth);
             const int n = n0 + tn, y = y0 + ty, xx = x0 + tx;
-            if (q >= npix || n >= a.N || y >= a.H || xx >= a.W || (x.ablate & 8)) continue;
+            if (q >= npix || n >= a.N || y >= a.H || xx >= a.W || CV_ABL(x, 8)) continue;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -683,7 +692,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
     }
     __syncthreads();
     stamp();
-    if (x.ablate & 8) return;
+    if (CV_ABL(x, 8)) return;
     // items in flight: the mask / skip-gradient loads of a batch are all issued before any is consumed.  (Measured: batches of
     // 6 or 12, or issuing the first batch before the accumulators are converted, are slower than batches of 4.)
     constexpr int EB = 4;

@@ -223,10 +223,14 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
         lod[i] = tx * g.DSTR + cc * 16;
     }
 
+#ifdef SSDN_TUNING
     int tr_i = 0;
     auto stamp = [&]() {
         if (x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)bx * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
     };
+#else
+    auto stamp = []() {};
+#endif
     stamp();
     // ---- double-buffered pipeline over this workgroup's tiles -------------------------------------------------------
     const int bufsz = g.XB + g.DB;

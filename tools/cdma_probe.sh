@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs a library built with `make -C selfsupervised-denoising_amd/csrc clean all TUNING=1`: the ablation bits and stamps are compiled out otherwise)
 # tuning aid: phase trace + ablations of k_cdma on the full-resolution 96->96 layer (run through gpurun)
 cd $GRAFT_REPO_ROOT
 export CONV_BENCH_ONLY_DEFAULT=1

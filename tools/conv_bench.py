@@ -119,7 +119,7 @@ def pair(*layers):
 
 
 def trace(layer="decode_block_1.2", role="fwd"):
-    """per-workgroup phase timeline from s_memtime stamps (ssdn_debug_set_trace)"""
+    """per-workgroup phase timeline from s_memtime stamps (ssdn_debug_set_trace); needs a `make TUNING=1` build of the library"""
     import ctypes as C
     import numpy as np
     B, P = 32, 64
