@@ -188,14 +188,19 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         if (CD_TUNING && x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
     };
     // waves 0-1: DMA of the weight slice (chunk c, halo tap tseq = 3i+j) into weight buffer `wpar`
-    auto issue_w = [&](int c, int tseq, int wpar) __attribute__((always_inline)) {
+    // byte offset of the (tap, chunk) slice in the chunk-major copy = wchunk(c) + wt0 + tseq * wts  (tseq = 3i+j of the halo tap; the
+    // mirrored window of the data-gradient role walks the taps backwards)
+    const int wtap = a.Mpad * a.Ktot * 2;
+    const int wt0 = x.rev ? 8 * wtap : 0, wts = x.rev ? -wtap : wtap;
+    auto wchunk = [&](int c) __attribute__((always_inline)) {
+        return __builtin_amdgcn_readfirstlane((c * 48 * a.Mpad + x.m_base * (c < x.nfull ? 48 : 16)) * 2 + wt0);
+    };
+    auto issue_w = [&](int wcb, bool full, int tseq, int wpar) __attribute__((always_inline)) {
         if (CD_ABL(x, 2)) return;
-        const int tw = x.rev ? 8 - tseq : tseq;
         const unsigned dst = wlds0 + wpar * WBYTES;
         // chunk-major pre-swizzled copy [tap][chunk][Mpad][kc] (ssdn_conv_args.wc, mandatory for this kernel): the slice IS the
         // LDS image -> linear 1 KiB pieces
-        const bool full = c < x.nfull;
-        const int sbase = ((tw * a.Mpad * a.Ktot) + c * 48 * a.Mpad + x.m_base * (full ? 48 : 16)) * 2;
+        const int sbase = wcb + tseq * wts;
         const int nq = full ? NWQ : MT;
 #pragma unroll
         for (int u = 0; u < NWU; ++u)
@@ -225,8 +230,9 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         const int xs = up ? xx >> 1 : xx;
         return ok ? (xs * cs + (cc ^ pr) * 8) * 2 : (int)0x80000000;
     };
-    auto issue_rows = [&](const CdTile& t, int c, int tpar, int rlE, int rlO, int u0, int nu) __attribute__((always_inline)) {
-        if (CD_ABL(x, 4)) return;
+    // everything about the rows of one (tile, chunk) that does not depend on the row: prepared ONCE per chunk, on the scalar unit
+    // (plain scalars, not a struct: in some instantiations a struct of them was placed in scratch)
+    auto row_ctx = [&](const CdTile& t, int c, int tpar, u32x4_t& o_rs, int& o_rbase, int& o_rstride, int& o_ybs, int& o_ush, unsigned& o_dst) __attribute__((always_inline)) {
         const int k0 = c * 48;
         const bool from0 = k0 < a.c0;
         const bool up = from0 && a.up0;
@@ -234,29 +240,32 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         const int cs = from0 ? a.src0.cs : a.src1.cs;
         const int cbase = from0 ? a.src0.co + k0 : a.src1.co + k0 - a.c0;
         const int Hs = up ? H0 : a.H, Ws = up ? W0 : a.W;
-        const int yb = t.y0 - x.padT;
-        const unsigned dst = tlds0 + tpar * CD_TBYTES;
-        const bool full = c < x.nfull;
+        // (readfirstlane: the values ARE wave-uniform; saying so once per chunk keeps the nine steps' row arithmetic on the
+        //  scalar unit -- the asm "s" operands of dma16 are not something the compiler would otherwise guarantee)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o_rs[q] = __builtin_amdgcn_readfirstlane(rs[q]);
+        o_rstride = __builtin_amdgcn_readfirstlane(Ws * cs * 2);
+        o_rbase = __builtin_amdgcn_readfirstlane((t.n * Hs * Ws * cs + cbase) * 2);
+        o_ybs = __builtin_amdgcn_readfirstlane(t.y0 - x.padT);
+        o_ush = up ? 1 : 0;
+        o_dst = __builtin_amdgcn_readfirstlane(tlds0 + tpar * CD_TBYTES);
+    };
+    auto issue_rows = [&](u32x4_t rc_rs, int rc_rbase, int rc_rstride, int rc_ybs, int rc_ush, unsigned rc_dst, bool full, int rlE, int rlO, int u0, int nu) __attribute__((always_inline)) {
+        if (CD_ABL(x, 4)) return;
         const bool act = full ? lane < 54 : lane < 36;
-        // everything about a row is scalar: byte offset of source row ys = rbase + ys * rstride (kept on the scalar unit:
-        // the inputs are made SGPR values here, so the compiler does not route the address through VALU + readfirstlane)
-        const int rstride = __builtin_amdgcn_readfirstlane(Ws * cs * 2);
-        const int rbase = __builtin_amdgcn_readfirstlane((t.n * Hs * Ws * cs + cbase) * 2);
-        const int ybs = __builtin_amdgcn_readfirstlane(yb);
-        const int ush = up ? 1 : 0;
 #pragma unroll
         for (int uu = 0; uu < 18; ++uu) {
             if (uu >= nu) break;               // (nu is a constant at every call site: the loop unrolls to nu items)
             const int r = lw + 2 * (u0 + uu);
             const int hy = full ? r >> 1 : r, half = full ? r & 1 : 0;
             if (hy >= 18) continue;
-            const int y = ybs + hy;
+            const int y = rc_ybs + hy;
             const bool rowok = (unsigned)y < (unsigned)a.H;
-            const int soff = rbase + (y >> ush) * rstride;                    // (an out-of-image row fetches nothing: voff is out of range)
+            const int soff = rc_rbase + (y >> rc_ush) * rc_rstride;            // (an out-of-image row fetches nothing: voff is out of range)
             const int voff = rowok ? ((hy & 1) ? rlO : rlE) : (int)0x80000000;
-            const unsigned ldsrow = dst + hy * (full ? 1728 : 576) + half * 864;
-            if (CD_ABL(x, 128)) { if (lane > 64) dma16(ldsrow, voff, rs, soff); }
-            else if (act) dma16(ldsrow, CD_ABL(x, 64) ? (int)0x80000000 : voff, rs, soff);
+            const unsigned ldsrow = rc_dst + hy * (full ? 1728 : 576) + half * 864;
+            if (CD_ABL(x, 128)) { if (lane > 64) dma16(ldsrow, voff, rc_rs, soff); }
+            else if (act) dma16(ldsrow, CD_ABL(x, 64) ? (int)0x80000000 : voff, rc_rs, soff);
         }
     };
 
@@ -276,8 +285,12 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // instruction that would land there are EXEC-masked)
     float* const bl = reinterpret_cast<float*>(smem + 18 * 18 * 96);
     if (tid < WROWS) bl[tid] = (a.bias && tid < x.m_cnt) ? a.bias[x.m_base + tid] : 0.f;
-    if (wload) issue_w(0, 0, 0);
-    else issue_rows(cur, 0, 0, row_lane(cur, 0, 0), row_lane(cur, 0, 1), 0, 18);
+    if (wload) issue_w(wchunk(0), 0 < x.nfull, 0, 0);
+    else {
+        u32x4_t q_rs; int q_rbase, q_rstride, q_ybs, q_ush; unsigned q_dst;
+        row_ctx(cur, 0, 0, q_rs, q_rbase, q_rstride, q_ybs, q_ush, q_dst);
+        issue_rows(q_rs, q_rbase, q_rstride, q_ybs, q_ush, q_dst, 0 < x.nfull, row_lane(cur, 0, 0), row_lane(cur, 0, 1), 0, 18);
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
@@ -323,14 +336,18 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             const bool pf_full = pc < x.nfull;
             int rlE = 0, rlO = 0;
             if (!wload && pf) { rlE = row_lane(pt, pc, 0); rlO = row_lane(pt, pc, 1); }
+            u32x4_t rc_rs; int rc_rbase, rc_rstride, rc_ybs, rc_ush; unsigned rc_dst;      // (unconditional: scalar values defined on one
+            row_ctx(pt, pc, tpar ^ 1, rc_rs, rc_rbase, rc_rstride, rc_ybs, rc_ush, rc_dst);  //  path only end up in VGPRs)
+            const int wcb_c = wchunk(c), wcb_p = wchunk(pc);
+            const bool cfull = c < x.nfull;
             // step head: the loaders start the fetches that must have landed one step (weights) / one chunk (tile) from now
             auto step_head = [&](int t) __attribute__((always_inline)) {
                 if (wload) {
-                    if (t < 8) issue_w(c, t + 1, wpar ^ 1);
-                    else if (pf) issue_w(pc, 0, wpar ^ 1);
+                    if (t < 8) issue_w(wcb_c, cfull, t + 1, wpar ^ 1);
+                    else if (pf) issue_w(wcb_p, pf_full, 0, wpar ^ 1);
                 } else if (pf && t < 8) {
-                    if (pf_full) issue_rows(pt, pc, tpar ^ 1, rlE, rlO, t < 2 ? 3 * t : 2 * t + 2, t < 2 ? 3 : 2);   // 18 row items per wave over steps 0..7
-                    else issue_rows(pt, pc, tpar ^ 1, rlE, rlO, t < 1 ? 0 : t + 1, t < 1 ? 2 : 1);                    // 9 row items per wave
+                    if (pf_full) issue_rows(rc_rs, rc_rbase, rc_rstride, rc_ybs, rc_ush, rc_dst, true, rlE, rlO, t < 2 ? 3 * t : 2 * t + 2, t < 2 ? 3 : 2);   // 18 row items per wave over steps 0..7
+                    else issue_rows(rc_rs, rc_rbase, rc_rstride, rc_ybs, rc_ush, rc_dst, false, rlE, rlO, t < 1 ? 0 : t + 1, t < 1 ? 2 : 1);            // 9 row items per wave
                 }
             };
             // step tail: own DMA landed, then ONE barrier: every wave's DMA landed and every wave is done with this step's buffers
