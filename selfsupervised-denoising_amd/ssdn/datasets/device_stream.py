@@ -38,12 +38,13 @@ class CleanPatches(Dataset):
 
 
 class DevicePatchStream:
-    def __init__(self, loader, noisy: NoisyDataset, device, seed: Optional[int] = None):
+    def __init__(self, loader, noisy: NoisyDataset, device, seed: Optional[int] = None, rank: int = 0):
         self.loader, self.noisy, self.device = loader, noisy, torch.device(device)
         self.generator = torch.Generator(device=self.device)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())      # drawn from the (checkpointed) host RNG
-        self.generator.manual_seed(seed)
+        self.seed = seed + rank            # ranks never share a noise stream, whatever their host RNG states are
+        self.generator.manual_seed(self.seed)
 
     def __len__(self) -> int:
         return len(self.loader)

@@ -15,6 +15,7 @@ tests/test_data_layer.py::test_h5lite_reads_a_libhdf5_written_file reads it back
 against files produced by `write_dataset_file` below (same subset, written from the specification).  Not covered: chunked or
 compressed datasets, new-style (v2) groups -- none of which the reference's converter produces.
 """
+import os
 import struct
 from typing import List, Tuple
 
@@ -29,19 +30,34 @@ class H5LiteError(RuntimeError):
 
 
 class _File:
+    """Positioned reads only (`os.pread`): the descriptor carries no file offset that forked DataLoader workers could race on
+    (a seek()+read() pair on an inherited descriptor did: corrupted images)."""
+
     def __init__(self, path: str):
-        self.f = open(path, "rb")
+        self.fd = os.open(path, os.O_RDONLY)
         self.base = 0
 
     def read(self, addr: int, n: int) -> bytes:
-        self.f.seek(self.base + addr)
-        b = self.f.read(n)
+        b = os.pread(self.fd, n, self.base + addr)
+        while 0 < len(b) < n:                       # (pread may return short on some filesystems)
+            more = os.pread(self.fd, n - len(b), self.base + addr + len(b))
+            if not more:
+                break
+            b += more
         if len(b) != n:
             raise H5LiteError("short read at %d (+%d)" % (addr, n))
         return b
 
     def close(self):
-        self.f.close()
+        if self.fd >= 0:
+            os.close(self.fd)
+            self.fd = -1
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 def _superblock(fh: _File) -> int:

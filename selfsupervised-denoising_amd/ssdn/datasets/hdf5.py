@@ -1,8 +1,11 @@
 """Dataset over a file written by `external/dataset_tool_h5.py` (drop-in for /root/reference/ssdn/ssdn/datasets/hdf5.py:19-100):
 `images` = variable-length uint8 (raw CHW bytes), `shapes` = int32 [N,3].  h5py is used when it is importable; otherwise the
 dependency-free reader `ssdn.datasets.h5lite` parses the one layout directly.  Unlike the reference (which re-opens the file
-for every item, hdf5.py:57-59) the file stays open per process.  Output tensors carry the reference's swapped H/W
+for every item, hdf5.py:57-59) the file stays open per PROCESS: a handle is never shared across fork (re-opened when the pid
+changes) and the dependency-free reader only uses positioned reads.  Output tensors carry the reference's swapped H/W
 (hdf5.py:62,71-72), see ssdn.datasets.folder."""
+import os
+
 import numpy as np
 import torch
 from PIL import Image
@@ -16,10 +19,13 @@ class HDF5Dataset(Dataset):
     def __init__(self, file_path: str, transform=None, h5_format: str = "CWH", output_format: str = "CHW", channels: int = 3):
         self.file_path, self.transform, self.output_format, self.channels, self.h5_format = file_path, transform, output_format, channels, h5_format
         self._h = None
+        self._pid = -1
         self.img_count = len(self._open())
+        self._h = None                          # no handle survives the constructor: every process (the parent too) opens its own
 
     def _open(self):
-        if self._h is None:
+        if self._h is None or self._pid != os.getpid():      # forked DataLoader workers inherit __dict__, not the handle
+            self._pid = os.getpid()
             try:
                 import h5py  # noqa: F401
                 self._h = _H5pyFile(self.file_path)

@@ -141,10 +141,11 @@ class Denoiser(nn.Module):
         return d
 
     def mark_dirty(self):
-        """The fp32 parameters changed: the fp16/bf16 MFMA shadows are re-packed before the next run.  Calling this by hand
-        is only needed after writing the flat buffer through a raw pointer; every torch-visible in-place update (a
-        `torch.optim` step on the parameters, `load_state_dict`, `p.data.copy_()` ...) is detected through the version counter
-        of the flat buffer, which all parameter views share."""
+        """The fp32 parameters changed: the fp16/bf16 MFMA shadows are re-packed before the next run.  In-place updates of the
+        parameters themselves (a `torch.optim` step, `load_state_dict`, `p.copy_()` under no_grad) are detected through the version
+        counter of the flat buffer, which all parameter views share.  Writes through `p.data` (its own version counter) or a raw
+        pointer are NOT: call this after them.  Evaluation-mode runs re-pack unconditionally (23 us), so a stale shadow can only
+        ever be seen by a training-mode forward that follows an undeclared `.data` write."""
         self._version += 1
         for m in self._models.values():
             if hasattr(m, "mark_dirty"):
@@ -176,7 +177,7 @@ class Denoiser(nn.Module):
                     self._last_train_engine = None
         slot = self._engines.pop(key)
         self._engines[key] = slot                            # most recently used last
-        if slot[1] != self._param_version():
+        if slot[1] != self._param_version() or not train:
             slot[0].repack()
             slot[1] = self._param_version()
         return slot[0]

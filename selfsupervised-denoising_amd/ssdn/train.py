@@ -46,25 +46,32 @@ logger = logging.getLogger("ssdn.train")
 
 class _RankShard(torch.utils.data.Sampler):
     """Batches of dataset indexes for ONE rank: the global order is cut into global minibatches and rank r takes rows
-    [r*B/W, (r+1)*B/W) of each (ssdn.hip.dp.shard_rows) -- a W-GPU run consumes the order of a 1-GPU run."""
+    [r*B/W, (r+1)*B/W) of each (ssdn.hip.dp.shard_rows) -- a W-GPU run consumes the order of a 1-GPU run.
+
+    Every rank yields the SAME number of batches (a rank that ran out early would leave the others blocked in the gradient
+    all-reduce): a final partial global minibatch -- TRAIN_ITERATIONS not a multiple of the global batch -- is NOT sharded,
+    every rank processes all of it (identical rows on every rank: the 1/W-averaged all-reduce is then the gradient of that
+    batch).  `counts` carries, in order, the number of GLOBAL samples each yielded batch stands for; the trainer advances
+    ITERATION (LR schedule, sampler index in checkpoints) by that, not by rows x world."""
 
     def __init__(self, sampler: FixedLengthSampler, global_batch: int, rank: int, world: int):
+        from collections import deque
         from ssdn.hip.dp import shard_rows
         self.sampler, self.global_batch = sampler, global_batch
         self.lo, self.hi = shard_rows(global_batch, rank, world)
+        self.counts = deque()
 
     def __iter__(self):
         batch = []
         for idx in self.sampler:
             batch.append(idx)
             if len(batch) == self.global_batch:
+                self.counts.append(self.global_batch)
                 yield batch[self.lo:self.hi]
                 batch = []
         if batch:
-            per = -(-len(batch) // max(1, self.global_batch // (self.hi - self.lo)))
-            part = batch[self.lo // (self.hi - self.lo) * per:][:per]
-            if part:
-                yield part
+            self.counts.append(len(batch))
+            yield batch
 
     def __len__(self):
         return -(-len(self.sampler) // self.global_batch)
@@ -83,9 +90,12 @@ class DenoiserTrainer:
         self._train_iter = None
         self.trainloader = self.trainset = self.train_sampler = None
         self.testloader = self.testset = self.test_sampler = None
+        # one process per GPU (torchrun environment): join the job and select this rank's device BEFORE anything is allocated
+        # (world 1: selects the device only; no GPU: gloo)
         from ssdn.hip import dp
-        self.rank, self.world, self.local_rank = dp.env_world()
+        self.rank, self.world, self.local_rank = dp.init_from_env()
         self._exchange = None
+        self._shard: Optional[_RankShard] = None
         self.device_data = None          # None: device-side patch preparation whenever a GPU is present (see train_data)
 
     # ---- target -----------------------------------------------------------------------------------------------------------
@@ -104,10 +114,23 @@ class DenoiserTrainer:
 
     def new_target(self):
         device = "cuda:%d" % self.local_rank if torch.cuda.is_available() else None
-        if self.world > 1:
-            torch.manual_seed(0)                 # identical replicas: every rank draws the same initial weights
         self.denoiser = Denoiser(self.cfg, device=device)
         self.init_state()
+
+    def _sync_replicas(self):
+        """Identical replicas: rank 0's parameters (and optimiser moments) go to every rank -- the user's seed, whatever it
+        was, decides the initial weights, and the ranks' RNG states stay different (noise realisations and Noise2Void masks must
+        not be correlated across the shards of a global minibatch)."""
+        if self.world <= 1:
+            return
+        import torch.distributed as dist
+        d = self._denoiser
+        for t in (d.flat, d.adam_m, d.adam_v):
+            dist.broadcast(t, src=0)
+        steps = torch.tensor([d.adam_steps], dtype=torch.int64, device=d.flat.device)
+        dist.broadcast(steps, src=0)
+        d.adam_steps = int(steps.item())
+        d.mark_dirty()
 
     def init_state(self):
         self.state[StateValue.INITIALISED] = True
@@ -128,6 +151,7 @@ class DenoiserTrainer:
         if self.denoiser is None:
             self.new_target()
         denoiser = self.denoiser
+        self._sync_replicas()                # whatever built or loaded the target: every rank starts from rank 0's weights
         if self.rank == 0:
             _ = self.writer
             ssdn.logging_helper.setup(self.run_dir_path, "log.txt")
@@ -178,7 +202,8 @@ class DenoiserTrainer:
                 for key in (PipelineOutput.NOISE_STD_DEV, PipelineOutput.MODEL_STD_DEV):
                     if key in outputs:
                         train_history[key.value] += outputs[key] * 255
-            self.state[StateValue.ITERATION] += image_count * self.world
+            # images consumed by the whole job: rows x world for a sharded minibatch, the true count for the un-sharded tail
+            self.state[StateValue.ITERATION] += self._shard.counts.popleft() if self._shard is not None else image_count
         logger.info(separator())
         logger.info("TRAINING FINISHED")
         logger.info(separator())
@@ -380,6 +405,9 @@ class DenoiserTrainer:
         self._train_iter = SamplingOrder.from_state_dict(state_dict["train_order_iter"])
         self.denoiser.load_optimizer_state_dict(state_dict["optimizer"])
         torch.set_rng_state(state_dict["rng"])
+        if self.world > 1 and self.rank > 0:
+            # the file holds rank 0's generator state: the other ranks continue from a state derived from it, not from a copy
+            torch.manual_seed(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()) + self.rank)
 
     # ---- data -------------------------------------------------------------------------------------------------------------
     def _open(self, path, dtype, transform):
@@ -421,13 +449,15 @@ class DenoiserTrainer:
             _ = iter(sampler)                        # materialise the order under the common seed, then reuse it
             sampler.for_next_iter(sampler.last_iter())
             torch.set_rng_state(g)
-            loader = DataLoader(source, batch_sampler=_RankShard(sampler, cfg[ConfigValue.TRAIN_MINIBATCH_SIZE], self.rank, self.world), **kw)
+            self._shard = _RankShard(sampler, cfg[ConfigValue.TRAIN_MINIBATCH_SIZE], self.rank, self.world)
+            loader = DataLoader(source, batch_sampler=self._shard, **kw)
         else:
+            self._shard = None
             loader = DataLoader(source, sampler=sampler, batch_size=cfg[ConfigValue.TRAIN_MINIBATCH_SIZE], **kw)
         if device_stream:
             dev = self.denoiser.device if self.denoiser is not None and hasattr(self.denoiser, "device") else \
                 torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
-            loader = DevicePatchStream(loader, dataset, dev)
+            loader = DevicePatchStream(loader, dataset, dev, rank=self.rank)
         return loader, dataset, sampler
 
     def set_train_data(self, path: str):
