@@ -1,14 +1,23 @@
 #!/usr/bin/env python
 """bench.py -- training patches/sec of the ssdn hot path on MI355X (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1: one rank per GPU over RCCL.  Launched by `torch.distributed.run` (RANK / WORLD_SIZE / LOCAL_RANK in the environment) the
+script is a rank; launched plainly with --gpus N > 1 it re-executes itself under `torch.distributed.run --nnodes=1
+--nproc-per-node N --master-addr 127.0.0.1` and relays rank 0's line.  Any failure is reported as ONE JSON line {"error": ...}.
 
 Workload (BASELINE.json configs[1], the configuration the metric is quoted on): ssdn gauss25 sigma_known, 64x64 RGB
 patches, batch 32 PER GPU (weak scaling), blind-spot U-Net + posterior head + SSDN loss + backward + gradient all-reduce
-+ fused Adam.  Synthetic data (clean ~ U[0,1), clipped N(0,(25/255)^2) noise), reference-style random-init weights;
-batches are resident in HBM when the timed region starts.  One "step" = one optimisation step on one minibatch.
++ fused Adam.  Synthetic data (clean uint8 patches ~ U{0..255}), reference-style random-init weights.  One "step" = one
+optimisation step on one minibatch, INCLUDING the batch's way to the device (SURVEY.md section 8(d) / BASELINE.md section 3: the
+metric "includes H2D of the batch"): the minibatch starts every step as clean uint8 patches in pinned HOST memory (what the
+DataLoader workers of the trainer deliver, 393 KB), is uploaded, and noise / rotation stack / fp16 NHWC packing happen on the
+device (`ssdn.datasets.DevicePatchStream`, the trainer's default data path on a GPU).
 
-Prints ONE JSON line (rank 0) with `value` = whole-job patches/s, plus
+Prints ONE JSON line (rank 0) with `value` = whole-job patches/s of that loop, plus
+  value_resident / value_with_fp32_h2d: the same step with the prepared batch already in HBM / arriving as fp32 noisy + clean
+                from pinned host memory (the reference's DataLoader format); side legs of >= 50 steps each, N = 1 only;
   roofline:     the dominant kernel (k_cdma<3,*>: the 96-output-channel 3x3 convolutions at 32x32 and 64x64 pixels, forward
                 and data-gradient role), timed with HIP events on the launch stream inside the timed region
                 (ssdn_profile_*), against the dense fp16 MFMA peak of /opt/skills/guides/MI355X_MICROARCH.md;
@@ -102,71 +111,156 @@ def cpu_baseline(P):
     med = statistics.median(times)
     return {"value": round(Bc / med, 3), "unit": "patches/s", "cores": best_threads, "kind": "port",
             "sample": "median of %d timed full training steps (fwd+loss+autograd bwd+Adam) after warm-up, batch %d, 64x64 RGB ssdn "
-                      "gauss25 sigma_known, torch-CPU fp32, %d threads (of %d physical cores; better of {all, half})"
+                      "gauss25 sigma_known, torch-CPU fp32, %d threads (of %d physical cores; better of {all, half}). Caveat: the port does "
+                      "not scale with cores (oneDNN on 64x64 patches: 64 threads here ~1.5x the reference on 8 cores, BASELINE.md 5.15 patches/s) -- a stated "
+                      "baseline, not a tuned CPU implementation"
                       % (n, Bc, best_threads, phys),
             "step_seconds": [round(t, 3) for t in times]}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
-    ap.add_argument("--patch", type=int, default=64)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
 
+
+def spawn_ranks(args) -> int:
+    """`python bench.py --gpus N` without a torchrun environment: run the N ranks under torch.distributed.run ourselves and relay
+    rank 0's JSON line; a job that dies without one is reported as {"error": ...} (e.g. RCCL's duplicate-device error when the
+    box has fewer GPUs than ranks), never as a bare traceback."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + \
+        [a for a in sys.argv[1:]]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    sys.stderr.write(p.stderr[-20000:])
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith("{") and ('"metric"' in ln or '"error"' in ln):
+            line = ln
+    if line is None:
+        tail = [ln for ln in p.stderr.splitlines() if ln.strip()][-12:]
+        line = json.dumps({"error": "bench.py --gpus %d: the %d-rank job exited with code %d without a result line" % (args.gpus, args.gpus, p.returncode),
+                           "n_gpus": args.gpus, "stderr_tail": tail})
+    print(line)
+    return 0 if (p.returncode == 0 and '"error"' not in line[:12]) else 1
+
+
+class _StubDenoiser:
+    """SSDN_BENCH_STUB=1 (tests/test_bench_dryrun.py, CPU): stands where `Denoiser` stands so that the launcher, the rank
+    sharding, the bucketed exchange driver, the timing protocol and the result line of THIS script run end to end over gloo
+    without a GPU.  It computes nothing of the workload; its line carries "stub": true and is never a measurement."""
+
+    def __init__(self, device):
+        from ssdn.hip.graph import net_layers, net_param_count
+        self.layers = net_layers(3, 9, True)
+        self.n = net_param_count(self.layers)
+        self.flat = torch.zeros(self.n, device=device)
+        self.flat_grad = torch.zeros(self.n, device=device)
+        self.device = device
+
+    def train(self):
+        pass
+
+    def gradient_exchange(self, world):
+        from ssdn.hip import dp
+        return dp.GradExchange(world, dp.bucket_ranges(self.layers, self.n, self.n), self.device)
+
+    def train_step(self, data, lr, exchange=None):
+        from ssdn.hip import dp
+        x = data[0]
+
+        def bwd(ex):
+            self.flat_grad.fill_(float(x.float().mean()))
+        scale = dp.exchange_step(bwd, self.flat_grad, exchange)
+        self.flat.sub_(lr * scale * self.flat_grad)
+        return {}
+
+
+def run_rank(args):
     import ssdn  # noqa: F401
-    from ssdn.denoiser import Denoiser
-    from ssdn.datasets import NoisyDataset
+    from ssdn.datasets import DevicePatchStream, NoisyDataset
     from ssdn.hip import dp, lib as L
+    from ssdn.params import NoiseAlgorithm
     from ssdn.utils.utils import compute_ramped_lrate
     import torch.distributed as dist
 
-    rank, world, local = dp.init_from_env()
+    stub = os.environ.get("SSDN_BENCH_STUB") == "1"
+    # SSDN_BENCH_BACKEND=gloo: ranks may share a GPU (device = LOCAL_RANK mod visible GPUs) and exchange device tensors through
+    # gloo -- how the whole N-rank path is exercised on the 1-GPU test boxes; RCCL itself refuses two ranks on one device
+    backend = "gloo" if stub else os.environ.get("SSDN_BENCH_BACKEND")
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    local_env = int(os.environ.get("LOCAL_RANK", 0))
+    rank, world, local = dp.init_from_env(backend, device_index=(local_env % ndev) if ndev else None)
+    if ndev:
+        local = local_env % ndev
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)" % (args.gpus, world))
-    device = torch.device("cuda", local)
-    torch.cuda.set_device(device)
-    lib = L.load()
-
-    torch.manual_seed(0)                      # identical replicas: same init on every rank
-    d = Denoiser(make_cfg(), device=str(device))
+        raise RuntimeError("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if stub:
+        device = torch.device("cpu")
+        lib = None
+        d = _StubDenoiser(device)
+    else:
+        if not torch.cuda.is_available():
+            raise L.SsdnHipError("bench.py needs an MI355X (no GPU visible); the ssdn hot path has no CPU fallback")
+        device = torch.device("cuda", local)
+        torch.cuda.set_device(device)
+        lib = L.load()
+        from ssdn.denoiser import Denoiser
+        torch.manual_seed(0)                      # identical replicas: same init on every rank
+        d = Denoiser(make_cfg(), device=str(device))
     d.train()
     B, P = args.batch, args.patch
     MD = NoisyDataset.Metadata
-    batches = []
-    for i in range(4):
-        noisy, clean = synth_batch(B, P, 1000 * (rank + 1) + i, device)
-        meta = {MD.INPUT_NOISE_VALUES: torch.full((B, 1, 1, 1), 25.0 / 255.0, device=device), MD.CLEAN: clean}
-        batches.append([noisy, clean, meta])
+
+    def sync():
+        if device.type == "cuda":
+            torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        sync()
+
+    # the minibatches as the trainer's DataLoader workers deliver them: clean uint8 patches in pinned host memory
+    g = torch.Generator().manual_seed(1000 * (rank + 1))
+    u8 = [torch.randint(0, 256, (B, 3, P, P), generator=g, dtype=torch.uint8) for _ in range(4)]
+    if device.type == "cuda":
+        u8 = [t.pin_memory() for t in u8]
+    nd = NoisyDataset(None, "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
+    stream = DevicePatchStream(None, nd, device, seed=1, rank=rank)
+    idx = torch.arange(B)
     exchange = d.gradient_exchange(world) if world > 1 else None    # bucketed all-reduce overlapped with backward
     N_IT = 2000000
     seen = 0
 
+    def lr_now():
+        return compute_ramped_lrate(seen + 200000, N_IT, 0.1, 0.3, 3e-4)   # flat part of the schedule
+
     def step(i):
+        """the measured step: pinned uint8 minibatch -> device -> noise + packing -> forward + loss + backward [+ all-reduce] + Adam"""
         nonlocal seen
-        lr = compute_ramped_lrate(seen + 200000, N_IT, 0.1, 0.3, 3e-4)   # flat part of the schedule
-        d.train_step(batches[i % len(batches)], lr, exchange)
+        d.train_step(stream.prepare(u8[i % len(u8)], idx), lr_now(), exchange)
         seen += B * world
 
     for i in range(args.warmup):
         step(i)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
     # roofline leg: HIP events around the launches of the dominant kernel, k_cdma<3,*> (the 96-output-channel 3x3 layers at
     # 32x32 and 64x64 pixels, forward and data-gradient roles: 8 launches per step, 60 % of the step's flops), on the launch
     # stream, during the timed steps.  An event pair costs ~10 us of stream time (it serialises what would be back-to-back
     # kernels), so only every 5th launch is bracketed -> the sample rotates over all eight layers.
-    prof_kind = L.PROF["cdma_mt3"]
     PROF_STRIDE = 5
-    lib.ssdn_profile_enable(prof_kind, 64 * args.steps // PROF_STRIDE + 64)
-    lib.ssdn_profile_set_stride(prof_kind, PROF_STRIDE)
+    if lib is not None:
+        prof_kind = L.PROF["cdma_mt3"]
+        lib.ssdn_profile_enable(prof_kind, 64 * args.steps // PROF_STRIDE + 64)
+        lib.ssdn_profile_set_stride(prof_kind, PROF_STRIDE)
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -178,60 +272,55 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ms, cnt, fl, by = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
-    L.check(lib.ssdn_profile_read(prof_kind, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
-    lib.ssdn_profile_enable(prof_kind, 0)
+    if lib is not None:
+        L.check(lib.ssdn_profile_read(prof_kind, C.byref(ms), C.byref(cnt), C.byref(fl), C.byref(by)))
+        lib.ssdn_profile_enable(prof_kind, 0)
 
     # ---- after the timed region (does not touch `value`) ----------------------------------------------------------------
     # (a) per-family table: every MFMA kernel family bracketed at stride 3 over a few extra steps
     families = {}
     FAM_STEPS, FAM_STRIDE = 12, 3
-    for name, kind in L.PROF.items():
-        lib.ssdn_profile_enable(kind, 80 * FAM_STEPS // FAM_STRIDE + 64)
-        lib.ssdn_profile_set_stride(kind, FAM_STRIDE)
-    for i in range(FAM_STEPS):
-        step(i)
-    torch.cuda.synchronize()
-    for name, kind in L.PROF.items():
-        m2, c2, f2, b2 = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
-        L.check(lib.ssdn_profile_read(kind, C.byref(m2), C.byref(c2), C.byref(f2), C.byref(b2)))
-        lib.ssdn_profile_enable(kind, 0)
-        if c2.value:
-            families[name] = {"sampled_launches": int(c2.value), "avg_launch_us": round(1e3 * m2.value / c2.value, 2),
-                              "tflops_algorithmic": round(f2.value / 1e12 / (m2.value / 1e3), 1) if m2.value > 0 else None,
-                              "launches_per_step": round(c2.value * FAM_STRIDE / FAM_STEPS, 1),
-                              "ms_per_step_bracketed_sum": round(m2.value * FAM_STRIDE / FAM_STEPS, 4)}
-    # (b) the same loop with the minibatch arriving from (pinned) host memory every step: the PCIe-inclusive rate of
-    # SURVEY.md section 8(d); reported next to `value`, never as `value`
-    h2d_value = u8_value = None
-    if world == 1:
-        host = [[b[0].cpu().pin_memory(), b[1].cpu().pin_memory(),
-                 {k: (v.cpu().pin_memory() if torch.is_tensor(v) else v) for k, v in b[2].items()}] for b in batches]
-        nh = max(10, args.steps // 4)
-        torch.cuda.synchronize()
-        th0 = time.perf_counter()
-        for i in range(nh):
+    if lib is not None:
+        for name, kind in L.PROF.items():
+            lib.ssdn_profile_enable(kind, 80 * FAM_STEPS // FAM_STRIDE + 64)
+            lib.ssdn_profile_set_stride(kind, FAM_STRIDE)
+        for i in range(FAM_STEPS):
+            step(i)
+        sync()
+        for name, kind in L.PROF.items():
+            m2, c2, f2, b2 = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+            L.check(lib.ssdn_profile_read(kind, C.byref(m2), C.byref(c2), C.byref(f2), C.byref(b2)))
+            lib.ssdn_profile_enable(kind, 0)
+            if c2.value:
+                families[name] = {"sampled_launches": int(c2.value), "avg_launch_us": round(1e3 * m2.value / c2.value, 2),
+                                  "tflops_algorithmic": round(f2.value / 1e12 / (m2.value / 1e3), 1) if m2.value > 0 else None,
+                                  "launches_per_step": round(c2.value * FAM_STRIDE / FAM_STEPS, 1),
+                                  "ms_per_step_bracketed_sum": round(m2.value * FAM_STRIDE / FAM_STEPS, 4)}
+    # (b) side legs (N = 1), >= SIDE_STEPS steps each whatever --steps says: the prepared batch already resident in HBM
+    # (kernel-only rate), and the reference's DataLoader format (fp32 noisy + clean from pinned host memory, 2 x 1.6 MB per step)
+    resident_value = fp32_value = None
+    SIDE_STEPS = max(50, args.steps // 2)
+    if world == 1 and not stub:
+        res_batches = [stream.prepare(u8[i], idx) for i in range(len(u8))]
+
+        def timed(fn):
+            for i in range(5):
+                fn(i)
+            sync()
+            t1 = time.perf_counter()
+            for i in range(SIDE_STEPS):
+                fn(i)
+            sync()
+            return round(SIDE_STEPS * B / (time.perf_counter() - t1), 2)
+        resident_value = timed(lambda i: d.train_step(res_batches[i % len(res_batches)], 3e-4, exchange))
+        host = [[b[0].cpu().pin_memory(), b[2][MD.CLEAN].cpu().pin_memory(), b[2][MD.INPUT_NOISE_VALUES].cpu().pin_memory()] for b in res_batches]
+
+        def fp32_step(i):
             hb = host[i % len(host)]
-            d.train_step([hb[0].to(device, non_blocking=True), hb[1].to(device, non_blocking=True),
-                          {k: (v.to(device, non_blocking=True) if torch.is_tensor(v) else v) for k, v in hb[2].items()}],
-                         3e-4, exchange)
-        torch.cuda.synchronize()
-        h2d_value = round(nh * B / (time.perf_counter() - th0), 2)
-        # (c) N2: the minibatch arrives as the CLEAN uint8 patches (393 KB) and noise / metadata are produced on the device
-        # (ssdn.datasets.DevicePatchStream.prepare -- what DenoiserTrainer does on a GPU)
-        from ssdn.datasets import DevicePatchStream, NoisyDataset
-        from ssdn.params import NoiseAlgorithm
-        nd = NoisyDataset(None, "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
-        stream = DevicePatchStream(None, nd, device, seed=1)
-        u8 = [(b[2][NoisyDataset.Metadata.CLEAN].cpu() * 255).round().to(torch.uint8).pin_memory() for b in batches]
-        idx = torch.arange(B)
-        for i in range(3):
-            d.train_step(stream.prepare(u8[i % len(u8)], idx), 3e-4, exchange)
-        torch.cuda.synchronize()
-        tu0 = time.perf_counter()
-        for i in range(nh):
-            d.train_step(stream.prepare(u8[i % len(u8)], idx), 3e-4, exchange)
-        torch.cuda.synchronize()
-        u8_value = round(nh * B / (time.perf_counter() - tu0), 2)
+            clean = hb[1].to(device, non_blocking=True)
+            d.train_step([hb[0].to(device, non_blocking=True), clean,
+                          {MD.INPUT_NOISE_VALUES: hb[2].to(device, non_blocking=True), MD.CLEAN: clean}], 3e-4, exchange)
+        fp32_value = timed(fp32_step)
 
     if rank == 0:
         value = args.steps * B * world / dt
@@ -239,7 +328,7 @@ def main():
         # HBM-side traffic of the same kernel family: PMC passes cannot run inside this process, so the per-launch figure is
         # the committed result of tools/pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE); null if absent
         traffic, traffic_src = None, None
-        for cand in ("r02_traffic.json",):      # the committed PMC summary of THIS kernel (tools/pmc_traffic.sh)
+        for cand in ("r03_traffic.json", "r02_traffic.json"):      # the committed PMC summary of THIS kernel (tools/pmc_traffic.sh)
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     tj = json.load(f)
@@ -252,28 +341,60 @@ def main():
             "metric": "training patches/sec (64x64 gauss25 SSDN)", "value": round(value, 2), "unit": "patches/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
-            "data": "synthetic (clean U[0,1), clipped gauss25 noise; random-init weights), resident in HBM",
-            "config": {"workload": "ssdn gauss25 sigma_known, %dx%d RGB patches, batch %d per GPU, blind-spot U-Net fwd+bwd + posterior head + Adam" % (P, P, B),
+            "data": "synthetic (clean uint8 patches U{0..255} in pinned host memory, uploaded EVERY step; clipped gauss25 noise made on the "
+                    "device; random-init weights)",
+            "config": {"workload": "ssdn gauss25 sigma_known, %dx%d RGB patches, batch %d per GPU, H2D of the minibatch + device noise + blind-spot U-Net fwd+bwd + posterior head + Adam" % (P, P, B),
                        "global_batch": B * world, "parallelism": "dp%d" % world,
                        "achieved_train_tflops_algorithmic": round(value * TRAIN_GFLOP_PER_PATCH / 1e3, 2)},
-            "roofline": {"bound": "mfma", "kernel": "k_cdma<3,*>: persistent LDS-DMA 3x3 convolution on 96-output-channel blocks (decode_block_1.*/2.*, forward + data-gradient roles, 8 launches per step); flops counted on REAL channels",
-                         "achieved": round(achieved, 2), "peak": MFMA_FP16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "traffic_unit": "HBM-side bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE from separate --pmc passes over this "
-                                         "command; NOT measured in this run: %s" % traffic_src,
-                         "algorithmic_bytes_per_launch": int(by.value / max(1, cnt.value)),
-                         "launches": int(cnt.value), "sampling": "every %dth launch of the timed region" % PROF_STRIDE, "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 3),
-                         "kernel_time_share": round(PROF_STRIDE * ms.value / 1e3 / dt, 4)},
         }
-        res["families"] = families
-        if h2d_value is not None:
-            res["value_with_h2d"] = h2d_value
-            res["value_with_device_patch_stream"] = u8_value
-        if world == 1 and not args.no_cpu_baseline:
+        if world > 1:
+            res["config"]["backend"] = backend or "nccl (RCCL)"
+        if stub:
+            res["stub"] = True
+            res["data"] = "STUB ENGINE (SSDN_BENCH_STUB=1, CPU dry run of the launcher / exchange / timing protocol): not a measurement"
+        else:
+            res["roofline"] = {"bound": "mfma", "kernel": "k_cdma<3,*>: persistent LDS-DMA 3x3 convolution on 96-output-channel blocks (decode_block_1.*/2.*, forward + data-gradient roles, 8 launches per step); flops counted on REAL channels",
+                               "achieved": round(achieved, 2), "peak": MFMA_FP16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                               "frac": round(achieved / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
+                               "traffic_unit": "HBM-side bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE from separate --pmc passes over this "
+                                               "command; NOT measured in this run: %s" % traffic_src,
+                               "algorithmic_bytes_per_launch": int(by.value / max(1, cnt.value)),
+                               "launches": int(cnt.value), "sampling": "every %dth launch of the timed region" % PROF_STRIDE, "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 3),
+                               "kernel_time_share": round(PROF_STRIDE * ms.value / 1e3 / dt, 4)}
+            res["families"] = families
+        if resident_value is not None:
+            res["value_resident"] = resident_value
+            res["value_with_fp32_h2d"] = fp32_value
+            res["side_leg_steps"] = SIDE_STEPS
+        if world == 1 and not args.no_cpu_baseline and not stub:
             res["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(res))
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
+    ap.add_argument("--patch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args))
+    try:
+        run_rank(args)
+    except BaseException as e:  # noqa: BLE001 -- the contract is ONE JSON line, also for failures
+        if isinstance(e, (SystemExit, KeyboardInterrupt)):
+            raise
+        import traceback
+        traceback.print_exc()
+        if int(os.environ.get("RANK", 0)) == 0:
+            print(json.dumps({"error": "%s: %s" % (type(e).__name__, str(e)[:2000]), "n_gpus": args.gpus}))
+        sys.exit(1)
 
 
 if __name__ == "__main__":

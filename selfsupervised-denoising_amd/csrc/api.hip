@@ -173,7 +173,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     // dirty[s][d]: lane s has enqueued work that lane d (which depends on s) has not been ordered after yet
     bool dirty[SSDN_NLANES][SSDN_NLANES] = {}, used[SSDN_NLANES] = {true, false, false, false};
     for (int d = 1; d < SSDN_NLANES; ++d) dirty[0][d] = true;   // whatever the caller enqueued before this list
-    static const bool one_lane = getenv("SSDN_ONE_LANE") != nullptr;   // tuning / debugging aid
+    static const bool one_lane = ssdn_tuning_env("SSDN_ONE_LANE") != nullptr;   // tuning / debugging aid
     LaneSet* LS = nullptr;
     for (int i = 0; i < n; ++i) {
         const void* p = ops[i].args;
@@ -204,7 +204,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_UNROT_FWD: rc = launch_unrot_fwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_UNROT_BWD: rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_WGRAD: {   // a run of consecutive small-layer weight-gradient GEMMs on the same lane is one launch
-                static const bool no_merge = getenv("SSDN_NO_WGRAD_MERGE") != nullptr;      // A/B aid, read once
+                static const bool no_merge = ssdn_tuning_env("SSDN_NO_WGRAD_MERGE") != nullptr;      // A/B aid, read once
                 const ssdn_wgrad_args* items[WGRAD_MULTI_MAX];
                 int m = 0;
                 while (!no_merge && m < WGRAD_MULTI_MAX && i + m < n && ops[i + m].type == SSDN_OP_WGRAD && ops[i + m].args &&

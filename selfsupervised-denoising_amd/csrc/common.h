@@ -3,6 +3,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/ssdn_hip.h"
+#include <cstdlib>
+
+// A/B and ablation knobs read the process environment ONLY in a `make TUNING=1` build (tools/*.sh build one); in the default
+// build the lookup is a constant nullptr, so the library's behaviour never depends on the environment.
+#if defined(SSDN_TUNING)
+static inline const char* ssdn_tuning_env(const char* name) { return std::getenv(name); }
+#else
+static inline const char* ssdn_tuning_env(const char*) { return nullptr; }
+#endif
 
 typedef _Float16 h16;
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));

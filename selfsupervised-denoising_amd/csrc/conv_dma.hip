@@ -626,9 +626,9 @@ int launch_conv_dma(const ssdn_conv_args* a, hipStream_t s) {
     x.tiles_x = a->W >> 4; x.tiles_y = a->H >> 4;
     x.segs = 1; x.tps = x.tiles_y; x.nitems = 0; x.xcd_map = 0;
     x.nfull = a->Ktot / 48; x.tail16 = (a->Ktot % 48) ? 1 : 0;
-    static const int env_ablate = [] { const char* e = getenv("SSDN_CDMA_ABLATE"); return e ? atoi(e) : 0; }();
+    static const int env_ablate = [] { const char* e = ssdn_tuning_env("SSDN_CDMA_ABLATE"); return e ? atoi(e) : 0; }();
     x.ablate = env_ablate;
-    static const int env_wrep = [] { const char* e = getenv("SSDN_CDMA_WREP"); return e ? atoi(e) : 0; }();
+    static const int env_wrep = [] { const char* e = ssdn_tuning_env("SSDN_CDMA_WREP"); return e ? atoi(e) : 0; }();
     x.wrep = env_wrep;
     x.trace = (unsigned long long*)ssdn_debug_get_trace();
     int rc = 0;

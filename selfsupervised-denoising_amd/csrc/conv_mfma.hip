@@ -766,7 +766,7 @@ __global__ __launch_bounds__(CONV_THREADS, 2) void k_conv(ssdn_conv_args a, Conv
 static bool conv_uses_mt1(const ssdn_conv_args* a, const ConvGeom& g) {
     static int mt1_tiles = -1;
     if (mt1_tiles < 0) {
-        const char* e = getenv("SSDN_CONV_MT1_TILES");       // tuning override
+        const char* e = ssdn_tuning_env("SSDN_CONV_MT1_TILES");       // tuning override
         mt1_tiles = e ? atoi(e) : ssdn_device_cus();
         if (mt1_tiles <= 0) mt1_tiles = 256;                  // no device (planning on a CPU-only host)
     }
@@ -776,7 +776,7 @@ static bool conv_uses_mt1(const ssdn_conv_args* a, const ConvGeom& g) {
 // which kernel serves a layer: 0 = always k_conv, 1 = k_cdma where its shape class fits AND the layer has >= 1 tile per CU
 // (default), 2 = k_cdma wherever the shape class fits (lets the test-suite drive it at fixture sizes).  Initial value from
 // the environment (SSDN_CONV_DMA, read once), changed with ssdn_conv_set_mode().
-static int g_conv_mode = [] { const char* e = getenv("SSDN_CONV_DMA"); return e ? atoi(e) : 1; }();
+static int g_conv_mode = [] { const char* e = ssdn_tuning_env("SSDN_CONV_DMA"); return e ? atoi(e) : 1; }();
 extern "C" int ssdn_conv_set_mode(int mode) {
     if (mode < 0 || mode > 2) return ssdn_set_error("conv mode must be 0, 1 or 2");
     g_conv_mode = mode;
@@ -825,7 +825,7 @@ int conv_lds_bytes(const ssdn_conv_args* a) {
 
 // FLAT: ALLW + the 256-pixel tile is made of whole images (see k_conv)
 static bool conv_flat_ok(const ssdn_conv_args* a, const ConvGeom& g, int ks, int threads) {
-    static const bool no_flat = getenv("SSDN_CONV_NO_FLAT") != nullptr;      // A/B aid, read once
+    static const bool no_flat = ssdn_tuning_env("SSDN_CONV_NO_FLAT") != nullptr;      // A/B aid, read once
     const int m_last = a->M - (a->Mpad - 32);                                // real channels of the last 32-channel block
     return !no_flat && threads == 256 && ks <= 4 && g.TW == a->W && g.TH == a->H && g.TN * g.TH * g.TW == 256 && a->N % g.TN == 0 &&
            (m_last == 32 || m_last == 16 || m_last == 8) && (!a->up0 || !((a->H | a->W) & 1));
@@ -851,7 +851,7 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     double bytes = px * (a->c0 * 2.0 / (a->up0 ? 4.0 : 1.0) + a->c1 * 2.0) + px * m_real * (a->dst32 ? 4.0 : 2.0);
     prof_begin(3 - MT, s);
     x.nblk = nblk_y;
-    static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;      // A/B aid, read once
+    static const bool no_allw = ssdn_tuning_env("SSDN_CONV_NO_ALLW") != nullptr;      // A/B aid, read once
     x.allw = (!no_allw && conv_allw(*a, g, MT, a->kc) && !conv_async(*a, a->kc)) ? 1 : 0;
     x.flat = (x.allw && conv_flat_ok(a, g, KS, CONV_THREADS)) ? 1 : 0;
     if (a->pool.p && !x.flat) return ssdn_set_error("conv: fused max-pool requested for a launch that does not take the flat path");
@@ -879,7 +879,7 @@ static int conv_launch_ks(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
 
 
 bool conv_fuses_pool(const ssdn_conv_args* a) {
-    static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;
+    static const bool no_allw = ssdn_tuning_env("SSDN_CONV_NO_ALLW") != nullptr;
     if (conv_validate(a) || a->bf16 || a->dst32 || !a->act || (a->H & 1) || (a->W & 1)) return false;
     if (conv_use_gemm(a)) return false;
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
@@ -889,7 +889,7 @@ bool conv_fuses_pool(const ssdn_conv_args* a) {
 }
 
 static bool conv_flat_path(const ssdn_conv_args* a) {
-    static const bool no_allw = getenv("SSDN_CONV_NO_ALLW") != nullptr;
+    static const bool no_allw = ssdn_tuning_env("SSDN_CONV_NO_ALLW") != nullptr;
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     const bool wide = a->ltw + a->lth + a->ltn > 8;
     return conv_uses_mt1(a, g) && !no_allw && conv_allw(*a, g, 1, a->kc) && !conv_async(*a, a->kc) &&
@@ -925,8 +925,8 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     x.m_base = 0;
     {
         // tuning aids, read ONCE per process (not on the launch path)
-        static const int env_ablate = [] { const char* e = getenv("SSDN_CONV_ABLATE"); return e ? atoi(e) : 0; }();
-        static const int env_desync = [] { const char* e = getenv("SSDN_CONV_DESYNC"); return e ? atoi(e) : 0; }();
+        static const int env_ablate = [] { const char* e = ssdn_tuning_env("SSDN_CONV_ABLATE"); return e ? atoi(e) : 0; }();
+        static const int env_desync = [] { const char* e = ssdn_tuning_env("SSDN_CONV_DESYNC"); return e ? atoi(e) : 0; }();
         x.ablate = env_ablate;
         x.trace = g_conv_trace;
         x.desync = env_desync;

@@ -749,7 +749,7 @@ static bool wgrad_thin_ok(const ssdn_wgrad_args* a);
 bool wgrad_mergeable(const ssdn_wgrad_args* a) {
     if (wgrad_thin_ok(a)) return false;                             // (has its own kernel)
     // layers of at most 128 images x 16 x 16 pixels: their own launch cannot fill the chip
-    static const long long small_px = [] { const char* e = getenv("SSDN_WGRAD_SMALL_PX"); return e ? atoll(e) : 32768ll; }();   // experiment knob, read once
+    static const long long small_px = [] { const char* e = ssdn_tuning_env("SSDN_WGRAD_SMALL_PX"); return e ? atoll(e) : 32768ll; }();   // experiment knob, read once
     if ((long long)a->N * a->H * a->W > small_px || a->mblocks > 1) return false;
     WgPrep p;
     if (wgrad_validate(a)) return false;
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(WGN_THREADS) void k_wgrad_thin(ssdn_wgrad_args a) {
     }
 }
 static bool wgrad_thin_ok(const ssdn_wgrad_args* a) {
-    static const bool off = getenv("SSDN_NO_THIN_WGRAD") != nullptr;      // A/B aid, read once
+    static const bool off = ssdn_tuning_env("SSDN_NO_THIN_WGRAD") != nullptr;      // A/B aid, read once
     if (off || a->kreal < 1 || a->kreal > 3 || a->ntaps != 9 || a->csplit > 1 || a->mblocks > 1) return false;
     if ((a->H & 15) || (a->W & 15) || (a->M & 7) || a->Mpad > 96 || a->Kpad < a->kreal) return false;
     if (a->c0 > 0 ? (a->up0 || a->c1 > 0) : a->c1 <= 0) return false;

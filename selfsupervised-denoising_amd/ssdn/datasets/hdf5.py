@@ -27,9 +27,13 @@ class HDF5Dataset(Dataset):
         if self._h is None or self._pid != os.getpid():      # forked DataLoader workers inherit __dict__, not the handle
             self._pid = os.getpid()
             try:
-                import h5py  # noqa: F401
-                self._h = _H5pyFile(self.file_path)
+                import h5py
+                real = isinstance(getattr(h5py, "__version__", None), str)      # (not an import stub left in sys.modules)
             except ImportError:
+                real = False
+            if real:
+                self._h = _H5pyFile(self.file_path)
+            else:
                 from ssdn.datasets.h5lite import ImageFile
                 self._h = ImageFile(self.file_path)
         return self._h

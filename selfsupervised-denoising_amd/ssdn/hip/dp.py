@@ -29,19 +29,21 @@ def env_world() -> Tuple[int, int, int]:
     return int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 
 
-def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
-    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun sets them)."""
+def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None) -> Tuple[int, int, int]:
+    """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun sets them) and select
+    this rank's GPU (LOCAL_RANK unless `device_index` says otherwise) before anything is allocated."""
     rank, world, local = env_world()
+    have_gpu = torch.cuda.is_available()
+    dev = local if device_index is None else device_index
+    if have_gpu:
+        torch.cuda.set_device(dev)
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = "nccl" if have_gpu else "gloo"
         if backend == "nccl":
-            torch.cuda.set_device(local)
-            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", local))
+            dist.init_process_group(backend, rank=rank, world_size=world, device_id=torch.device("cuda", dev))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
-    elif torch.cuda.is_available():
-        torch.cuda.set_device(local)
     return rank, world, local
 
 
@@ -146,10 +148,3 @@ def exchange_step(run_backward: Callable[[Optional[GradExchange]], None], flat_g
         return 1.0
     exchange.launch(flat_grad)
     return exchange.finish()
-
-
-class GradAllReduce(GradExchange):
-    """Back-compatible name: one bucket = the whole flat buffer (no overlap)."""
-
-    def __init__(self, world: int):
-        super().__init__(world, [])
