@@ -243,10 +243,14 @@ def run_rank(args):
     def lr_now():
         return compute_ramped_lrate(seen + 200000, N_IT, 0.1, 0.3, 3e-4)   # flat part of the schedule
 
+    pending = stream.upload(u8[0])
+
     def step(i):
-        """the measured step: pinned uint8 minibatch -> device -> noise + packing -> forward + loss + backward [+ all-reduce] + Adam"""
-        nonlocal seen
-        d.train_step(stream.prepare(u8[i % len(u8)], idx), lr_now(), exchange)
+        """the measured step: pinned uint8 minibatch -> device (EVERY step; the copy of minibatch i + 1 runs on the patch stream's
+        copy stream under step i, as in DevicePatchStream.__iter__) -> noise kernel -> forward + loss + backward [+ all-reduce] + Adam"""
+        nonlocal seen, pending
+        cur, pending = pending, stream.upload(u8[(i + 1) % len(u8)])
+        d.train_step(stream.prepare(cur, idx), lr_now(), exchange)
         seen += B * world
 
     for i in range(args.warmup):

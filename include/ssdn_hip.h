@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSDN_ABI_VERSION 5
+#define SSDN_ABI_VERSION 6
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -61,8 +61,9 @@ enum ssdn_op_type {
     SSDN_OP_ADAM = 17,
     SSDN_OP_SQERR = 18,
     SSDN_OP_ZERO = 19,
-    SSDN_OP_EVENT_RECORD = 20 /* hipEventRecord(event) on the op's lane: lets a consumer outside the list (the gradient
-                                 all-reduce on its own stream) wait for a PREFIX of the list */
+    SSDN_OP_EVENT_RECORD = 20, /* hipEventRecord(event) on the op's lane: lets a consumer outside the list (the gradient
+                                  all-reduce on its own stream) wait for a PREFIX of the list */
+    SSDN_OP_NOISE = 21         /* training patch stream: uint8 clean patches -> noisy / clean / reference fp32 (+ Noise2Void) */
 };
 
 /* One record of the op list.  `args` points at the matching ssdn_*_args struct (host memory).
@@ -371,6 +372,42 @@ typedef struct ssdn_zero_args {
 typedef struct ssdn_event_args {
     void* event;
 } ssdn_event_args;
+
+/* ---- SSDN_OP_NOISE --------------------------------------------------------------------------
+ * replaces the per-sample preparation of the training stream, reference ssdn/ssdn/datasets/noise_wrapper.py:66-135 with
+ * utils/noise.py:54-107 (add_gaussian / add_poisson) and utils/n2v_ups.py:40-88 (Noise2Void pixel selection), for a whole
+ * minibatch of CLEAN uint8 patches already on the device:
+ *     clean   = u8 / 255
+ *     param   = p_lo                                   if p_lo == p_hi
+ *               U[p_lo, p_hi) per (sample, CHANNEL)    otherwise (the reference draws a ranged parameter per leading index of an
+ *                                                      unbatched CHW sample, i.e. per channel: noise.py:34-39,55-56)
+ *     gauss:    noisy = clean + param * N(0,1)                       (param = std dev as a fraction of 1)
+ *     poisson:  noisy = (clean * param + Poisson(1)) / param         (RATE-1 noise on lambda x: the reference's quirk, noise.py:101-104)
+ *     clip:     noisy = min(max(noisy, 0), 1)
+ * `ref32` (optional) is a second, independent realisation with its own parameter draw (the Noise2Noise / Noise2Void reference).  With n2v_box > 0 the
+ * first realisation is manipulated like n2v_ups.manipulate: one pixel (c0, c1) per n2v_box x n2v_box box (c0 stratified over W,
+ * c1 over H, uniform inside the box), replaced in every channel by the noisy value of a pixel drawn uniformly from
+ * [min(c - r, 0), min(c + r, size - 1)) without c itself, per axis (the reference's window: [0, c + r) in the interior, negative
+ * indexes wrap like Python's); coords[b][i * (H / box) + j] = (c0, c1) as the reference returns them (image[:, c1, c0] is the
+ * replaced pixel).  Random numbers: Philox4x32-10 keyed by `seed`, counter = (element, stream, offset): stateless, every launch
+ * must pass a fresh `offset`.  The distributions are the reference's; the random STREAM is not torch's (parity of the noise is
+ * statistical by construction). */
+typedef struct ssdn_noise_args {
+    const void* clean_u8; /* [B,C,H,W] uint8 */
+    float* clean32;       /* out [B,C,H,W] or NULL */
+    float* noisy32;       /* out [B,C,H,W] */
+    float* ref32;         /* out [B,C,H,W] or NULL */
+    float* param;         /* out [B*C] or NULL: the parameter of the first realisation */
+    float* param_ref;     /* out [B*C] or NULL: the (independently drawn) parameter of the second realisation */
+    int64_t* coords;      /* out [B, (W/box)*(H/box), 2] or NULL (required when n2v_box > 0) */
+    int32_t B, C, H, W;
+    int32_t style;        /* 0 gauss, 1 poisson */
+    int32_t clip;
+    float p_lo, p_hi;
+    int32_t n2v_box;      /* 0: no manipulation */
+    int32_t n2v_radius;   /* sub-patch radius (2 for the reference's 5 x 5) */
+    uint64_t seed, offset;
+} ssdn_noise_args;
 
 /* Execute `n` ops in order on `stream`.  Returns 0 or a negative error (ssdn_last_error()). */
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream);

@@ -86,6 +86,7 @@ int ssdn_struct_size(int op_type) {
         case SSDN_OP_SQERR: return (int)sizeof(ssdn_sqerr_args);
         case SSDN_OP_ZERO: return (int)sizeof(ssdn_zero_args);
         case SSDN_OP_EVENT_RECORD: return (int)sizeof(ssdn_event_args);
+        case SSDN_OP_NOISE: return (int)sizeof(ssdn_noise_args);
         default: return -1;
     }
 }
@@ -242,6 +243,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_MASK_MSE: rc = launch_mse((const ssdn_mse_args*)p, 1, s); break;
             case SSDN_OP_ADAM: rc = launch_adam((const ssdn_adam_args*)p, s); break;
             case SSDN_OP_SQERR: rc = launch_sqerr((const ssdn_sqerr_args*)p, s); break;
+            case SSDN_OP_NOISE: rc = launch_noise((const ssdn_noise_args*)p, s); break;
             case SSDN_OP_ZERO: {
                 const ssdn_zero_args* z = (const ssdn_zero_args*)p;
                 if (z->bytes & 15) return ssdn_set_error("op %d: zero size must be a multiple of 16", i);

@@ -112,6 +112,7 @@ int launch_spatial_mean(const ssdn_spatial_mean_args* a, hipStream_t s);
 int launch_mse(const ssdn_mse_args* a, int masked, hipStream_t s);
 int launch_adam(const ssdn_adam_args* a, hipStream_t s);
 int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s);
+int launch_noise(const ssdn_noise_args* a, hipStream_t s);
 int conv_lds_bytes(const ssdn_conv_args* a);
 // conv_dma.hip: persistent LDS-DMA convolution for the 3x3 layers that carry the flops
 bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size);

@@ -537,3 +537,124 @@ int launch_adam(const ssdn_adam_args* a, hipStream_t s) {
     hipLaunchKernelGGL(k_adam, dim3(g), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// NOISE: the training patch stream's per-sample work for a whole minibatch (noise_wrapper.py:66-135, utils/noise.py:54-107,
+// utils/n2v_ups.py:40-88).  One thread per pixel, all channels; HBM-bound: 1 byte in, 4-12 bytes out per element.
+// Random numbers are counter-based (Philox4x32-10): the value of element e of stream s of launch `offset` is a pure function of
+// (seed, offset, s, e), so the Noise2Void replacement can RE-DERIVE the noisy value of the neighbour it copies (no second pass).
+// ------------------------------------------------------------------------------------------------
+struct Ph4 { unsigned v[4]; };
+static __device__ __forceinline__ Ph4 philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const unsigned n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0; c1 = lo1; c2 = n2; c3 = lo0;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    Ph4 o;
+    o.v[0] = c0; o.v[1] = c1; o.v[2] = c2; o.v[3] = c3;
+    return o;
+}
+static __device__ __forceinline__ float u01(unsigned x) { return (float)(x >> 8) * (1.f / 16777216.f) + (0.5f / 16777216.f); }   // (0, 1)
+enum { NS_INPUT = 0, NS_REF = 1, NS_PARAM = 2, NS_COORD = 3, NS_PARAM_REF = 4 };
+// noisy value of element e (channel plane index bc = b*C + c) of realisation `stream`
+static __device__ __forceinline__ float noise_apply(const ssdn_noise_args& a, float clean, float param, unsigned e, unsigned stream) {
+    const Ph4 r = philox4x32_10(e, stream, (unsigned)a.offset, (unsigned)(a.offset >> 32), (unsigned)a.seed, (unsigned)(a.seed >> 32));
+    float v;
+    if (a.style == 0) {
+        const float z = sqrtf(-2.f * __logf(u01(r.v[0]))) * __cosf(6.28318530718f * u01(r.v[1]));      // Box-Muller
+        v = clean + param * z;
+    } else {
+        // Poisson(1) by inversion: P(k) = e^-1 / k!
+        const float u = u01(r.v[0]);
+        float pk = 0.36787944117f, cdf = pk;
+        int k = 0;
+        while (u > cdf && k < 16) { ++k; pk /= (float)k; cdf += pk; }
+        v = (clean * param + (float)k) / param;
+    }
+    if (a.clip) v = fminf(fmaxf(v, 0.f), 1.f);
+    return v;
+}
+static __device__ __forceinline__ float noise_param(const ssdn_noise_args& a, int bc, unsigned stream) {
+    if (a.p_lo == a.p_hi) return a.p_lo;
+    const Ph4 r = philox4x32_10((unsigned)bc, stream, (unsigned)a.offset, (unsigned)(a.offset >> 32), (unsigned)a.seed, (unsigned)(a.seed >> 32));
+    return a.p_lo + (a.p_hi - a.p_lo) * u01(r.v[0]);
+}
+// uniform integer over [lo, hi) without c (at least one candidate is assumed; n2v_ups.py:40-46); negative results wrap (Python indexing)
+static __device__ __forceinline__ int n2v_pick(int c, int r, int size, float u) {
+    const int lo = c - r < 0 ? c - r : 0, hi = c + r < size - 1 ? c + r : size - 1;
+    int span = hi - lo - (c >= lo && c < hi ? 1 : 0);
+    if (span < 1) span = 1;
+    int k = (int)(u * (float)span);
+    if (k >= span) k = span - 1;
+    int v = lo + k;
+    if (c >= lo && c < hi && v >= c) ++v;
+    if (v < 0) v += size;
+    if (v >= size) v = size - 1;
+    return v;
+}
+__global__ void k_noise(ssdn_noise_args a) {
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int H = a.H, W = a.W, HW = H * W;
+    if (idx >= (unsigned)(a.B * HW)) return;
+    const int x = idx % W, y = (idx / W) % H, b = idx / HW;
+    const unsigned char* u8 = (const unsigned char*)a.clean_u8;
+    // Noise2Void: is (x, y) the selected pixel of its box, and if so which neighbour does it copy?
+    bool blind = false;
+    int rx = x, ry = y;
+    if (a.n2v_box > 0) {
+        const int box = a.n2v_box, n1 = H / box, i = x / box, j = y / box, cell = i * n1 + j;
+        const unsigned ce = (unsigned)(b * (W / box) * n1 + cell);
+        const Ph4 r = philox4x32_10(ce, NS_COORD, (unsigned)a.offset, (unsigned)(a.offset >> 32), (unsigned)a.seed, (unsigned)(a.seed >> 32));
+        int c0 = i * box + (int)(u01(r.v[0]) * (float)box), c1 = j * box + (int)(u01(r.v[1]) * (float)box);
+        c0 = c0 > i * box + box - 1 ? i * box + box - 1 : c0;
+        c1 = c1 > j * box + box - 1 ? j * box + box - 1 : c1;
+        if (c0 == x && c1 == y) {
+            blind = true;
+            rx = n2v_pick(c0, a.n2v_radius, W, u01(r.v[2]));
+            ry = n2v_pick(c1, a.n2v_radius, H, u01(r.v[3]));
+            a.coords[((long long)b * (W / box) * n1 + cell) * 2 + 0] = c0;
+            a.coords[((long long)b * (W / box) * n1 + cell) * 2 + 1] = c1;
+        }
+    }
+    for (int c = 0; c < a.C; ++c) {
+        const int bc = b * a.C + c;
+        const unsigned e = (unsigned)(bc * HW + y * W + x);
+        const float clean = (float)u8[e] / 255.f;                 // (a true division, like to_tensor's: x * (1/255) differs in the last bit)
+        const float param = noise_param(a, bc, NS_PARAM);
+        float v;
+        if (blind) {
+            const unsigned en = (unsigned)(bc * HW + ry * W + rx);
+            v = noise_apply(a, (float)u8[en] / 255.f, param, en, NS_INPUT);
+        } else {
+            v = noise_apply(a, clean, param, e, NS_INPUT);
+        }
+        a.noisy32[e] = v;
+        if (a.clean32) a.clean32[e] = clean;
+        if (a.ref32) {
+            const float pr = noise_param(a, bc, NS_PARAM_REF);
+            a.ref32[e] = noise_apply(a, clean, pr, e, NS_REF);
+            if (a.param_ref && x == 0 && y == 0) a.param_ref[bc] = pr;
+        }
+        if (a.param && x == 0 && y == 0) a.param[bc] = param;
+    }
+}
+int launch_noise(const ssdn_noise_args* a, hipStream_t s) {
+    if (!a->clean_u8 || !a->noisy32) return ssdn_set_error("noise: clean_u8 and noisy32 are required");
+    if (a->B < 1 || a->C < 1 || a->H < 1 || a->W < 1) return ssdn_set_error("noise: empty shape");
+    const long long n = (long long)a->B * a->C * a->H * a->W;
+    if (n >= (1ll << 31)) return ssdn_set_error("noise: too many elements for 32-bit indexing");
+    if (a->style != 0 && a->style != 1) return ssdn_set_error("noise: style must be 0 (gauss) or 1 (poisson)");
+    if (a->style == 1 && !(a->p_lo > 0.f)) return ssdn_set_error("noise: poisson lambda must be > 0");
+    if (a->p_hi < a->p_lo) return ssdn_set_error("noise: p_hi < p_lo");
+    if (a->n2v_box > 0) {
+        if (!a->coords) return ssdn_set_error("noise: Noise2Void manipulation needs a coords output");
+        if (a->H % a->n2v_box || a->W % a->n2v_box) return ssdn_set_error("noise: H and W must be multiples of n2v_box");
+        if (a->n2v_radius < 1 || a->W < 2 || a->H < 2) return ssdn_set_error("noise: n2v_radius must be >= 1 and the patch larger than 1 pixel");
+    }
+    hipLaunchKernelGGL(k_noise, dim3(ew_grid((long long)a->B * a->H * a->W)), dim3(EW_BLOCK), 0, s, *a);
+    return 0;
+}

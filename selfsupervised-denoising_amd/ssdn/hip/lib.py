@@ -15,7 +15,7 @@ MAX_TAPS = 9
 # op type codes (enum ssdn_op_type)
 OP = dict(pack_input=1, conv=2, pool_fwd=3, pool_bwd=4, upsum_bwd=5, unrot_fwd=6, unrot_bwd=7, wgrad=8, wreduce=9,
           wpack=10, grad_pack=11, head_ssdn=12, head_final=13, spatial_mean=14, mse=15, mask_mse=16, adam=17,
-          sqerr=18, zero=19, event_record=20)
+          sqerr=18, zero=19, event_record=20, noise=21)
 
 i32, f32, vp = C.c_int32, C.c_float, C.c_void_p
 
@@ -114,13 +114,19 @@ class EventArgs(C.Structure):
     _fields_ = [("event", vp)]
 
 
+class NoiseArgs(C.Structure):
+    _fields_ = [("clean_u8", vp), ("clean32", vp), ("noisy32", vp), ("ref32", vp), ("param", vp), ("param_ref", vp), ("coords", vp),
+                ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("style", i32), ("clip", i32), ("p_lo", f32), ("p_hi", f32),
+                ("n2v_box", i32), ("n2v_radius", i32), ("seed", C.c_uint64), ("offset", C.c_uint64)]
+
+
 ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, pool_bwd=PoolArgs, upsum_bwd=UpsumArgs,
                  unrot_fwd=UnrotArgs, unrot_bwd=UnrotArgs, wgrad=WgradArgs, wreduce=WreduceArgs, wpack=WpackArgs,
                  grad_pack=GradPackArgs, head_ssdn=HeadArgs, head_final=HeadFinalArgs, spatial_mean=SpatialMeanArgs,
-                 mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs, event_record=EventArgs)
+                 mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 5      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 6      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",

@@ -82,7 +82,8 @@ def manipulate_batch(images: Tensor, subpatch_size: int = 5, generator=None):
         span = (hi - lo - 1).clamp(min=1)                     # candidates in [lo, hi) minus the centre
         k = (torch.rand(c.shape, device=dev, generator=generator) * span).long()
         v = lo + k
-        return torch.where(v >= c, v + 1, v).clamp(min=0, max=size - 1)
+        v = torch.where(v >= c, v + 1, v).clamp(max=size - 1)
+        return torch.where(v < 0, v + size, v)                # a negative draw indexes from the far edge, like the reference's Python indexing
     rx, ry = pick(x, W), pick(y, H)
     out = images.clone()
     bi = torch.arange(B, device=dev).view(B, 1).expand_as(x)

@@ -168,8 +168,10 @@ def test_n2v_pixel_selection(contract):
         diff = (outs[b] != imgs[b]).any(0)
         ys, xs = diff.nonzero(as_tuple=True)
         assert set(zip(xs.tolist(), ys.tolist())) <= {(int(x), int(y)) for x, y in cs[b].tolist()}
-        for x, y in cs[b].tolist():                     # the replacement comes from the reference's window [0, c + 2]
-            src = (imgs[b][:, :y + 3, :x + 3] == outs[b][:, y, x].view(3, 1, 1)).all(0)
+        for x, y in cs[b].tolist():                     # the replacement comes from the reference's window [min(c - 2, 0), c + 2): [0, c + 2)
+            cand_x = [v % 64 for v in range(min(x - 2, 0), min(x + 2, 63) + 1)]      # in the interior, wrapped negative draws near the edge
+            cand_y = [v % 64 for v in range(min(y - 2, 0), min(y + 2, 63) + 1)]
+            src = (imgs[b][:, cand_y][:, :, cand_x] == outs[b][:, y, x].view(3, 1, 1)).all(0)
             assert bool(src.any())
 
 
