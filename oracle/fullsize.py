@@ -1,0 +1,48 @@
+"""TEST INFRASTRUCTURE -- deterministic inputs of the FULL-SIZE parity fixtures (BASELINE.json config 2: ssdn gauss25 sigma_known,
+batch 32, 64x64 RGB -- the workload bench.py times; config 5, one rank's shard: ssdn poisson30 sigma_const, batch 16, 128x128).
+
+Used by oracle/gen_golden_fullsize.py (live reference -> tests/golden/g_full_*.npz), tests/test_oracle_golden.py (restatement vs
+those fixtures, CPU) and tests/test_hip_fullsize.py (device vs those fixtures, GPU).  Images are smooth synthetic textures
+(sums of oriented sinusoids + a blob: the regime the network trains in; hash-noise images make LeakyReLU branches of near-zero
+activations flip under 16-bit storage and say little about training); noise follows the reference's styles, drawn with fixed
+torch CPU generators (same torch build here and on the GPU box)."""
+import torch
+
+CASES = {
+    #  tag      algorithm style       mode     B   P
+    "cfg2": ("ssdn", "gauss25", "known", 32, 64),
+    "cfg5": ("ssdn", "poisson30", "const", 16, 128),
+}
+
+
+def textures(n, P, seed):
+    """smooth random RGB textures in [0,1]: sums of a few oriented sinusoids + a soft blob, different per image"""
+    g = torch.Generator().manual_seed(seed)
+    yy, xx = torch.meshgrid(torch.arange(P, dtype=torch.float32), torch.arange(P, dtype=torch.float32), indexing="ij")
+    out = torch.zeros(n, 3, P, P)
+    for i in range(n):
+        img = torch.zeros(3, P, P)
+        for _ in range(4):
+            fx, fy, ph = (torch.rand(3, generator=g) * torch.tensor([0.5, 0.5, 6.28])).tolist()
+            amp = torch.rand(3, generator=g).view(3, 1, 1) * 0.25
+            img += amp * torch.sin(xx * fx + yy * fy + ph)
+        cx, cy, r = (torch.rand(3, generator=g) * torch.tensor([P, P, P / 3]) + torch.tensor([0, 0, 4.0])).tolist()
+        img += 0.3 * torch.exp(-((xx - cx) ** 2 + (yy - cy) ** 2) / (2 * r * r)) * (torch.rand(3, generator=g).view(3, 1, 1) - 0.5)
+        out[i] = (img + 0.5).clamp(0, 1)
+    return out
+
+
+def inputs(tag):
+    """-> (clean [B,3,P,P], noisy, noise parameter [B,1,1,1]); 8-bit clean images like the data layer's"""
+    alg, style, mode, B, P = CASES[tag]
+    clean = (textures(B, P, 4242 + P) * 255).round() / 255
+    g = torch.Generator().manual_seed(7 + P)
+    if style.startswith("gauss"):
+        sigma = 25 / 255.0
+        noisy = (clean + torch.randn(clean.shape, generator=g) * sigma).clamp(0, 1)
+        npar = torch.full((B, 1, 1, 1), sigma)
+    else:                       # the reference's Poisson style: rate-1 noise on lambda x (utils/noise.py:101-104)
+        lam = 30.0
+        noisy = ((clean * lam + torch.poisson(torch.ones(clean.shape), generator=g)) / lam).clamp(0, 1)
+        npar = torch.full((B, 1, 1, 1), lam)
+    return clean, noisy, npar

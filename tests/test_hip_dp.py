@@ -106,3 +106,26 @@ def test_two_rank_train_step_equals_single_process():
     # (a weight whose gradient is ~0 may step the other way after a last-bit difference: Adam's first steps are sign-like)
     frac_off = float(np.mean(np.abs(upd_w - upd_g) > 0.5 * 3e-4))
     assert frac_off <= 0.01, frac_off
+    # Why not bit-equal to the single-process run: every rank's weight-gradient kernels sum THEIR shard's pixels in fp32 and the
+    # all-reduce adds the per-rank sums, (a + b) + (c + d), where the single process sums a + b + c + d inside one launch -- a
+    # different association of the same fp32 terms.  What IS bit-exact is asserted above: both ranks end with identical weights.
+    # ... and against the ORACLE on the whole minibatch (reference semantics: mean over the global batch, train.py:201): the same
+    # two optimisation steps in fp32 on the CPU, from the same weights
+    import restate as R
+    from ssdn.denoiser import Denoiser
+    net = d.get_model(Denoiser.MODEL, False)
+    d0 = _make()
+    net0 = d0.get_model(Denoiser.MODEL, False)
+    p_init = {k.replace("output_conv", "output_block.4"): v.detach().cpu().clone() for k, v in net0.state_dict().items() if not k.startswith("output_conv")}
+    tr = R.CpuTrainer("ssdn", 3, "gauss25", "known", params=p_init)
+    npar = torch.full((4, 1, 1, 1), 25 / 255.0)
+    for _ in range(2):
+        tr.step(3e-4, noisy, None, npar)
+    upd_o = np.zeros(n, dtype=np.float32)
+    for l in net.layers:
+        upd_o[l.w_off:l.w_off + l.M * l.cin * l.k * l.k] = tr.p[l.name + ".weight"].detach().reshape(-1).numpy()
+        upd_o[l.b_off:l.b_off + l.M] = tr.p[l.name + ".bias"].detach().numpy()
+    upd_o -= p0
+    cos_o = float((upd_o * upd_g).sum() / (np.linalg.norm(upd_o) * np.linalg.norm(upd_g) + 1e-30))
+    print("2-rank update vs oracle full-batch update: cosine %.5f (vs single-process HIP run %.5f)" % (cos_o, cos))
+    assert cos_o >= 0.99, cos_o          # measured 0.9957 (deterministic: identical in repeated runs)

@@ -106,6 +106,98 @@ def test_config5_shard_ssdn_poisson_sigma_const_b16_128():
     _run_config("ssdn", "poisson30", "const", 16, 128, loss_rtol=2e-2, min_cos=0.98, min_agree=0.94)
 
 
+# Bounds = 2-4x what this test measured on MI355X (profiles/r03_parity_fullsize.txt is its own output).  Config 2 (the bench
+# workload) is well conditioned: loss 4.0e-4, PSNR 0.002 dB, gradient norms 5.6e-3, per-layer cosine >= 0.99994.  Config 5
+# (Poisson noise with an estimated scale at random-init weights) is not -- the Poisson variance mu / lambda sits at its clamp for
+# many pixels, and two kernel selections of THIS library whose activations differ by one fp16 ulp differ by 5e-3 in the loss
+# (tools/path_compare.py) -- hence its looser numbers: loss 4.8e-3, gradient norms 5.8e-2, worst layer cosine 0.988.
+FULL_BOUNDS = {
+    #        loss rel (vs reference)  PSNR dB   per-tensor |g| rel, first entries / |g|   per-layer / whole-gradient cosine (vs oracle)
+    "cfg2": dict(loss=1.5e-3, psnr=0.01, gnorm=2e-2, ghead=2e-2, layer_cos=0.9998, cos=0.99995),
+    "cfg5": dict(loss=1.2e-2, psnr=0.04, gnorm=0.12, ghead=0.15, layer_cos=0.975, cos=0.995),
+}
+
+
+@pytest.mark.parametrize("tag", ["cfg2", "cfg5"])
+def test_full_size_vs_live_reference_fixture(golden_dir, tag):
+    """The sizes the bench and the config-5 shard RUN, against what the LIVE REFERENCE produced there (tests/golden/g_full_*.npz,
+    oracle/gen_golden_fullsize.py: its own Denoiser.run_pipeline + mean(LOSS).backward() on oracle/fullsize.py's inputs): per-sample
+    loss, per-image PSNR of the posterior mean, probes of the denoised image and of mu, per-tensor gradient norms -- and, next to
+    the oracle (which tests/test_oracle_golden.py pins to the same fixture at 2e-4 / 2e-3), per-layer gradient cosines."""
+    import numpy as np
+    import fullsize as F
+    from ssdn.denoiser import Denoiser
+    from ssdn.datasets import NoisyDataset
+    from ssdn.params import PipelineOutput
+    from test_hip_denoiser import _flat_of
+    from test_oracle_golden import param_name_map
+    g = np.load(os.path.join(golden_dir, "g_full_%s.npz" % tag), allow_pickle=False)
+    alg, style, mode, B, P = F.CASES[tag]
+    bnd = FULL_BOUNDS[tag]
+    d = make_denoiser(alg, style, mode, 3)
+    d.train()
+    tr = R.CpuTrainer(alg, 3, style, mode, params=R.make_params(3, 9, True, seed=5))
+    net = d.get_model(Denoiser.MODEL, False)
+    nets = [(net, 0, tr.p)]
+    d.flat.copy_(_flat_of(d, nets, tr))
+    d.mark_dirty()
+    clean, noisy, npar = F.inputs(tag)
+    MD = NoisyDataset.Metadata
+    out = d.run_pipeline([noisy, clean, {MD.INPUT_NOISE_VALUES: npar, MD.CLEAN: clean}])
+    d.backward()
+    torch.cuda.synchronize()
+    lines = ["%s: %s %s sigma_%s, batch %d, %dx%d" % (tag, alg, style, mode, B, P, P)]
+    # ---- against the reference fixture ----
+    loss, ref_loss = out[PipelineOutput.LOSS].detach().cpu().reshape(-1), torch.from_numpy(g["loss"]).reshape(-1)
+    loss_rel = float((loss - ref_loss).abs().max() / ref_loss.abs().max())
+    lines.append("  loss: max |dev - ref| / max |ref| = %.3e   (bound %.1e)" % (loss_rel, bnd["loss"]))
+    pme, mu = out[PipelineOutput.IMG_DENOISED].cpu(), out[PipelineOutput.IMG_MU].cpu()
+    probe = float((pme[:, :, 3::16, 5::16] - torch.from_numpy(g["out_probe"])).abs().max())
+    probe_mu = float((mu[:, :, 3::16, 5::16] - torch.from_numpy(g["mu_probe"])).abs().max())
+    dps = max(abs(float(R.psnr(pme[b:b + 1], clean[b:b + 1])) - float(g["psnr_out"][b])) for b in range(B))
+    lines.append("  posterior mean probe: max abs diff %.3e; mu probe %.3e; per-image PSNR max |diff| %.4f dB (bound %.2f)" % (probe, probe_mu, dps, bnd["psnr"]))
+    gd = d.flat_grad.cpu()
+    worst_gn = worst_head = 0.0
+    for name, (which, key) in param_name_map(g["names"]).items():
+        if which == "est":
+            o = d._n_main + d._n_sig
+            mine, headm = float(gd[o].abs()), gd[o:o + 1]
+        else:
+            l = next(x for x in net.layers if key.startswith(x.name + "."))
+            sl = slice(l.w_off, l.w_off + l.M * l.cin * l.k * l.k) if key.endswith("weight") else slice(l.b_off, l.b_off + l.M)
+            mine, headm = float(gd[sl].double().norm()), gd[sl][:16]
+        want = float(g["gnorm/" + name])
+        rel = abs(mine - want) / (want + 1e-12)
+        worst_gn = max(worst_gn, rel)
+        href = torch.from_numpy(g["ghead/" + name]).reshape(-1)
+        worst_head = max(worst_head, float((headm[:href.numel()] - href).abs().max()) / (want + 1e-12))
+    lines.append("  per-tensor gradient norm: max relative difference %.3e (bound %.1e); first 16 entries of every tensor: max |diff| / |g| %.3e (bound %.1e)" % (
+        worst_gn, bnd["gnorm"], worst_head, bnd["ghead"]))
+    # ---- against the oracle (pinned to the same fixture by the CPU suite): direction of every layer's gradient ----
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    r = tr.forward(noisy, clean, npar)
+    r["loss"].mean().backward()
+    gr = _flat_grad_of(d, nets, tr)
+    n = d._n_main + (1 if tr.est is not None else 0)
+    gd64, gr64 = gd.double(), gr.double()
+    cos_all = float((gd64[:n] * gr64[:n]).sum() / (gd64[:n].norm() * gr64[:n].norm() + 1e-300))
+    worst_cos, worst_layer = 1.0, ""
+    for l in net.layers:
+        sl = slice(l.w_off, l.w_off + l.M * l.cin * l.k * l.k)
+        c = float((gd64[sl] * gr64[sl]).sum() / (gd64[sl].norm() * gr64[sl].norm() + 1e-300))
+        if c < worst_cos:
+            worst_cos, worst_layer = c, l.name
+    agree = float(((gd[:n] > 0) == (gr[:n] > 0)).float().mean())
+    lines.append("  gradient vs fp32 oracle: whole cosine %.6f (bound %.4f), worst layer %s %.6f (bound %.4f), sign agreement %.4f" % (
+        cos_all, bnd["cos"], worst_layer, worst_cos, bnd["layer_cos"], agree))
+    os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
+    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fullsize_%s.txt" % tag), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    print("\n".join(lines))
+    assert loss_rel <= bnd["loss"] and dps <= bnd["psnr"] and worst_gn <= bnd["gnorm"] and worst_head <= bnd["ghead"], lines
+    assert cos_all >= bnd["cos"] and worst_cos >= bnd["layer_cos"], lines
+
+
 @pytest.mark.parametrize("P", [512, 768])
 def test_eval_sizes_forward_vs_oracle(P):
     """Evaluation shapes: batch 2 at 512x512 (BSD300) and 768x768 (Kodak), forward only, ssdn gauss25 sigma_known."""

@@ -206,6 +206,31 @@ def test_param_grads(golden_dir, tag, alg, style, mode, ch):
         close(t.grad.reshape(-1)[:16], g["ghead/" + name], rtol=5e-3, atol=1e-6 + 1e-4 * gn)
 
 
+@pytest.mark.parametrize("tag", ["cfg2", "cfg5"])
+def test_full_size_oracle_vs_reference(golden_dir, tag):
+    """The restatement at the sizes the bench and the config-5 shard RUN (batch 32 at 64x64; batch 16 at 128x128) against what the
+    live reference produced there (oracle/gen_golden_fullsize.py): per-sample loss, per-tensor gradient norm and first entries,
+    probes of the posterior mean and of mu, per-image PSNR."""
+    import fullsize as F
+    g = G(golden_dir, "g_full_" + tag)
+    alg, style, mode, B, P = F.CASES[tag]
+    tr = R.CpuTrainer(alg, 3, style, mode, params=R.make_params(3, 9, True, seed=5))
+    clean, noisy, npar = F.inputs(tag)
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    r = tr.forward(noisy, clean, npar)
+    r["loss"].mean().backward()
+    close(r["loss"], g["loss"], rtol=2e-4, atol=1e-4)
+    close(r["out"].detach()[:, :, 3::16, 5::16], g["out_probe"], rtol=1e-3, atol=5e-5)
+    close(r["out_mu"].detach()[:, :, 3::16, 5::16], g["mu_probe"], rtol=1e-3, atol=5e-5)
+    for b in range(B):
+        assert float(R.psnr(r["out"].detach()[b:b + 1], clean[b:b + 1])) == pytest.approx(float(g["psnr_out"][b]), abs=2e-3)
+    for name, (net, key) in param_name_map(g["names"]).items():
+        t = tr.est if net == "est" else tr.p[key]
+        gn = float(t.grad.double().norm())
+        assert gn == pytest.approx(float(g["gnorm/" + name]), rel=2e-3, abs=1e-7), name
+        close(t.grad.reshape(-1)[:16], g["ghead/" + name], rtol=5e-3, atol=1e-6 + 2e-4 * gn)
+
+
 def test_checkpoint_contract(golden_dir):
     ck = json.load(open(os.path.join(golden_dir, "g_ckpt_contract.json")))
     k = ck["ssdn_known"]
