@@ -105,14 +105,15 @@ class DeviceNet:
         the flat gradient is only read after the backward list.  Returns (records, layer name of each record if it is a
         reduction else None)."""
         from .dp import bucket_layers
-        if os.environ.get("SSDN_NO_WREDUCE_GROUPS") or not plan.bwd:
+        if not plan.bwd:
             return recs, [op.a.get("layer") if op.type == "wreduce" else None for op in plan.bwd]
         buckets = bucket_layers(plan.layers)
         bucket_of = {name: k for k, b in enumerate(buckets) for name in b}
         # The weight-gradient GEMMs of the layers at 16x16 pixels and below are issued together, where the last of them
         # stood: the executor runs a run of consecutive small SSDN_OP_WGRAD ops as ONE launch (k_wgrad_multi; same rule as
         # csrc/wgrad_mfma.hip::wgrad_mergeable).  Legal for the same reason: a side-lane op may always be delayed.
-        small = lambda op: op.type == "wgrad" and op.a["N"] * op.a["H"] * op.a["W"] <= int(os.environ.get("SSDN_WGRAD_SMALL_PX", "32768")) and not os.environ.get("SSDN_NO_WGRAD_GROUPS")  # noqa: E731
+        from .graph import WGRAD_SMALL_PX
+        small = lambda op: op.type == "wgrad" and op.a["N"] * op.a["H"] * op.a["W"] <= WGRAD_SMALL_PX  # noqa: E731
         # (one run per gradient bucket, so that a bucket still completes where it did)
         flush_at = {}                                   # index of the last small wgrad of each bucket
         for i, op in enumerate(plan.bwd):
@@ -148,29 +149,6 @@ class DeviceNet:
                         names.append(name_k)
                     pending[k] = []
         return out, names
-
-    @staticmethod
-    def _batch_side_ops(recs, every: Optional[int] = None):
-        """Re-order the backward list so that the side-lane ops (weight-gradient GEMMs + slab reductions) are issued in
-        batches, after every `every`-th main-lane convolution instead of right after the op that produced their input.
-        Delaying a side-lane op is always legal (it only reads tensors that are written once per step); each lane switch
-        costs the main stream an event record, so fewer switches = fewer bubbles."""
-        if every is None:
-            every = int(os.environ.get("SSDN_SIDE_BATCH", "1"))
-        if every <= 1:
-            return recs
-        out, pending, nconv = [], [], 0
-        for r in recs:
-            if r[0] in OpList.LANE:
-                pending.append(r)
-                continue
-            out.append(r)
-            if r[0] == "conv":
-                nconv += 1
-                if nconv % every == 0:
-                    out += pending
-                    pending = []
-        return out + pending
 
     # ---- helpers ------------------------------------------------------------------------------------------
     def tensor(self, short: str) -> torch.Tensor:

@@ -17,7 +17,12 @@ from typing import Dict, List, Optional, Tuple
 LDS_LIMIT = 160 * 1024
 # conv tilings at or below this many bytes of LDS are preferred: two workgroups then share a CU, so one workgroup's
 # tile staging / barriers overlap the other's MFMA work (tunable for experiments)
-CONV_LDS_PREFERRED = int(os.environ.get("SSDN_CONV_LDS_PREFERRED", 80 * 1024))
+CONV_LDS_PREFERRED = 80 * 1024
+# Planner constants of the weight-gradient family (measured on BASELINE config 2; module constants, NOT environment switches: the
+# plan a process makes never depends on its environment)
+WGRAD_SMALL_PX = 32768        # layers with at most this many pixels (16x16 and below at BASELINE sizes) share merged launches ...
+SMALL_WGRAD_G, SMALL_WGRAD_CUS = 2, 64      # ... planned as two column groups on <= 64 / 2 pixel partitions
+MID_WGRAD_PX, MID_WGRAD_G = 131072, 2       # the 32x32 stage: two column groups on half the partitions
 TAPS_BLIND = [(ky - 2, kx - 1) for ky in range(3) for kx in range(3)]   # ShiftConv2d: in[y+ky-2, x+kx-1]
 TAPS_PLAIN = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 TAPS_1x1 = [(0, 0)]
@@ -298,14 +303,13 @@ class NetPlan:
         Ktot = c0 + c1
         Mpad = ceil_to(M, 32)
         ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None, cus=self.cus)
-        fused = pool is not None and conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus) and \
-            not os.environ.get("SSDN_NO_POOL_FUSION")
+        fused = pool is not None and conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus)
         if upsum is not None:
             # fused SSDN_OP_UPSUM_BWD: k_cdma (>= one 16x16 tile per CU, whole 96-channel blocks) or k_conv's flat path
             dma = (len(taps) == 9 and H % 16 == 0 and W % 16 == 0 and N * (H // 16) * (W // 16) >= self.dev_cus and
                    Ktot % 48 in (0, 16) and upsum_c % 96 == 0)
             fused = (dma or conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus)) and upsum_c % 8 == 0 and \
-                mask is None and add is None and not os.environ.get("SSDN_NO_UPSUM_FUSION")
+                mask is None and add is None
             if not fused:
                 upsum = upsum_mask = None
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
@@ -351,11 +355,11 @@ class NetPlan:
             # persistent grids for 3/4 of the CUs keeps both lanes running side by side (measured on BASELINE config 2, two
             # boxes: 256 -> 2.35 ms, 208 -> 2.35, 192 -> 2.27 / 2.30, 160 -> 2.29, 128 -> 2.29 ms per step) and trims the slab
             # traffic by a quarter.
-            wcus = int(os.environ.get("SSDN_WGRAD_CUS", 0)) or (self.cus if self.cus < 64 else (3 * self.cus // 4) & ~7)
+            wcus = self.cus if self.cus < 64 else (3 * self.cus // 4) & ~7
             cus_eff = max(1, wcus // G)
             if small and small_g > 0:
                 cus_eff = max(1, min(self.cus, small_cus) // G)
-            if mblocks > 1 and not os.environ.get("SSDN_HEAD_FULL_SLABS"):
+            if mblocks > 1:
                 # the mblocks workgroups of a pixel partition run side by side: cus / mblocks partitions fill the chip in ONE
                 # round with 1/mblocks of the slab traffic (output_block.0: 38 MB instead of 151 MB written and read back)
                 cus_eff = max(1, wcus // mblocks)
@@ -366,23 +370,20 @@ class NetPlan:
             return t, tile, ns
 
         best = None
-        groups = [1] if (mblocks > 1 or os.environ.get("SSDN_NO_CSPLIT")) else sorted({1, 2, 3, 4, -(-ctiles // 4)})
+        groups = [1] if mblocks > 1 else sorted({1, 2, 3, 4, -(-ctiles // 4)})
         # Layers of at most 32768 pixels run inside ONE merged launch per gradient bucket (k_wgrad_multi) and get their
         # parallelism from each other: two column groups on 32 pixel partitions each (a few tiles per workgroup) instead of
         # up to seven groups that every one stage the same tiles -- measured on BASELINE config 2: -85 us per step against the
         # per-layer optimum (G = 1 on 32..64 partitions is equal within noise but needs the 21-accumulator instances).
-        small = N * H * W <= int(os.environ.get("SSDN_WGRAD_SMALL_PX", "32768")) and mblocks == 1 and cblocks is None and \
-            not os.environ.get("SSDN_NO_WGRAD_GROUPS")
-        small_g = int(os.environ.get("SSDN_SMALL_WGRAD_G", "2"))
-        small_cus = int(os.environ.get("SSDN_SMALL_WGRAD_CUS", "64"))
+        small = N * H * W <= WGRAD_SMALL_PX and mblocks == 1 and cblocks is None
+        small_g, small_cus = SMALL_WGRAD_G, SMALL_WGRAD_CUS
         default_groups = list(groups)
         if small and small_g > 0:
             groups = [small_g]
-        elif mblocks == 1 and cblocks is None and N * H * W <= int(os.environ.get("SSDN_MID_WGRAD_PX", "131072")) and \
-                int(os.environ.get("SSDN_MID_WGRAD_G", "2")) > 0:
+        elif mblocks == 1 and cblocks is None and N * H * W <= MID_WGRAD_PX and MID_WGRAD_G > 0:
             # the 32x32 stage: two column groups on half the partitions -- the cycle model (which prices a launch alone on
             # the chip) prefers one group; in situ half the slab traffic wins (-45 us per step, measured)
-            groups = [int(os.environ.get("SSDN_MID_WGRAD_G", "2"))]
+            groups = [MID_WGRAD_G]
         for attempt in (groups, default_groups):
             for G in attempt:
                 if G > 1 and 4 * -(-ctiles // (4 * G)) * (G - 1) >= ctiles:
@@ -534,7 +535,7 @@ class NetPlan:
         lo0 = L["output_block.0"]
         self._wgrad(lo0, View(g_na), 96, View(head_in), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, cblocks=blocks, mblocks=nin // 96)
         g_d1b = self.grad("g_d1b", N, H, W, 96)
-        if bs and H == W and H & (H - 1) == 0 and (B * H * W) % 256 == 0 and not os.environ.get("SSDN_NO_UNROT_FUSION"):
+        if bs and H == W and H & (H - 1) == 0 and (B * H * W) % 256 == 0:
             # the data-gradient GEMM scatters its four 96-channel blocks straight into the rotated tensors (fused
             # SSDN_OP_UNROT_BWD, k_gdma; the library's rule: csrc/gemm_dma.hip::gemm_dma_eligible)
             dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, None, unrot=View(g_d1b), unrot_mask=View(d1b))
