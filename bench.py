@@ -235,6 +235,8 @@ def run_rank(args):
         u8 = [t.pin_memory() for t in u8]
     nd = NoisyDataset(None, "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
     stream = DevicePatchStream(None, nd, device, seed=1, rank=rank)
+    if not stub:
+        stream.attach(d)              # the noise kernel writes the engine's input buffer directly (as the trainer's stream does)
     idx = torch.arange(B)
     exchange = d.gradient_exchange(world) if world > 1 else None    # bucketed all-reduce overlapped with backward
     N_IT = 2000000
@@ -305,7 +307,8 @@ def run_rank(args):
     resident_value = fp32_value = None
     SIDE_STEPS = max(50, args.steps // 2)
     if world == 1 and not stub:
-        res_batches = [stream.prepare(u8[i], idx) for i in range(len(u8))]
+        side = DevicePatchStream(None, nd, device, seed=2, rank=rank)         # (not attached: four distinct resident batches)
+        res_batches = [side.prepare(u8[i], idx) for i in range(len(u8))]
 
         def timed(fn):
             for i in range(5):

@@ -241,7 +241,19 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_SPATIAL_MEAN: rc = launch_spatial_mean((const ssdn_spatial_mean_args*)p, s); break;
             case SSDN_OP_MSE: rc = launch_mse((const ssdn_mse_args*)p, 0, s); break;
             case SSDN_OP_MASK_MSE: rc = launch_mse((const ssdn_mse_args*)p, 1, s); break;
-            case SSDN_OP_ADAM: rc = launch_adam((const ssdn_adam_args*)p, s); break;
+            case SSDN_OP_ADAM: {    // ... directly followed by the re-packs of its layers: one launch (k_adam_pack)
+                const ssdn_wpack_args* items[ADAM_PACK_MAX];
+                int m = 0;
+                while (m < ADAM_PACK_MAX && i + 1 + m < n && ops[i + 1 + m].type == SSDN_OP_WPACK && ops[i + 1 + m].args &&
+                       (one_lane ? 0 : ops[i + 1 + m].lane) == lane)
+                    items[m] = (const ssdn_wpack_args*)ops[i + 1 + m].args, ++m;
+                const bool whole_run = !(i + 1 + m < n && ops[i + 1 + m].type == SSDN_OP_WPACK);      // (never split a run of re-packs)
+                if (m > 0 && whole_run && adam_pack_fusable((const ssdn_adam_args*)p, items, m)) {
+                    rc = launch_adam_pack((const ssdn_adam_args*)p, items, m, s);
+                    i += m;
+                } else rc = launch_adam((const ssdn_adam_args*)p, s);
+                break;
+            }
             case SSDN_OP_SQERR: rc = launch_sqerr((const ssdn_sqerr_args*)p, s); break;
             case SSDN_OP_NOISE: rc = launch_noise((const ssdn_noise_args*)p, s); break;
             case SSDN_OP_ZERO: {

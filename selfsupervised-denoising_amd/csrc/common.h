@@ -111,6 +111,9 @@ int launch_head_final(const ssdn_head_final_args* a, hipStream_t s);
 int launch_spatial_mean(const ssdn_spatial_mean_args* a, hipStream_t s);
 int launch_mse(const ssdn_mse_args* a, int masked, hipStream_t s);
 int launch_adam(const ssdn_adam_args* a, hipStream_t s);
+#define ADAM_PACK_MAX 24
+int adam_pack_fusable(const ssdn_adam_args* a, const ssdn_wpack_args* const* items, int n);
+int launch_adam_pack(const ssdn_adam_args* a, const ssdn_wpack_args* const* items, int n, hipStream_t s);
 int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s);
 int launch_noise(const ssdn_noise_args* a, hipStream_t s);
 int conv_lds_bytes(const ssdn_conv_args* a);

@@ -517,19 +517,82 @@ int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s) {
 // ------------------------------------------------------------------------------------------------
 // ADAM  (train.py:100-107,202): one fused pass over the flat master buffer
 // ------------------------------------------------------------------------------------------------
+// one element of the Adam update (shared by k_adam and k_adam_pack: the two must round identically; explicit fmaf / no re-association)
+static __device__ __forceinline__ float adam_elem(const ssdn_adam_args& a, long long i, float inv_bc2s, float step) {
+    const float g = a.g[i] * a.gscale;
+    const float m = __fmaf_rn(a.b1, a.m[i], __fmul_rn(1.f - a.b1, g));
+    const float v = __fmaf_rn(a.b2, a.v[i], __fmul_rn(__fmul_rn(1.f - a.b2, g), g));
+    a.m[i] = m;
+    a.v[i] = v;
+    const float den = __fmaf_rn(sqrtf(v), inv_bc2s, a.eps);
+    const float pn = __fsub_rn(a.p[i], __fdiv_rn(__fmul_rn(step, m), den));
+    a.p[i] = pn;
+    return pn;
+}
 __global__ void k_adam(ssdn_adam_args a) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     long long stride = (long long)gridDim.x * blockDim.x;
     float inv_bc2s = 1.f / sqrtf(a.bc2);
     float step = a.lr / a.bc1;
+    for (; i < a.n; i += stride) adam_elem(a, i, inv_bc2s, step);
+}
+// ADAM + WPACK in one pass (the executor fuses an SSDN_OP_ADAM that is directly followed by the SSDN_OP_WPACK ops of layers whose
+// weights lie in its range): the thread that updates a weight also writes its 16-bit images into the MFMA shadows -- the value it
+// just computed, converted exactly as k_wpack converts it (bit-identical shadows; the padding of the shadows is never rewritten, it
+// stays the zeros of the first re-pack).  Saves the re-pack launch after every optimiser step (23 us) and one read of the parameters.
+struct AdamPackTable {
+    ssdn_adam_args a;
+    ssdn_wpack_args e[ADAM_PACK_MAX];
+    long long w_off[ADAM_PACK_MAX];     // first element of the layer's weight tensor in the Adam range (ascending)
+    int n;
+};
+__global__ void k_adam_pack(AdamPackTable t) {
+    const ssdn_adam_args& a = t.a;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const float inv_bc2s = 1.f / sqrtf(a.bc2);
+    const float step = a.lr / a.bc1;
     for (; i < a.n; i += stride) {
-        float g = a.g[i] * a.gscale;
-        float m = a.b1 * a.m[i] + (1.f - a.b1) * g;
-        float v = a.b2 * a.v[i] + (1.f - a.b2) * g * g;
-        a.m[i] = m;
-        a.v[i] = v;
-        a.p[i] -= step * m / (sqrtf(v) * inv_bc2s + a.eps);
+        const float pn = adam_elem(a, i, inv_bc2s, step);
+        int j = 0;
+        while (j + 1 < t.n && i >= t.w_off[j + 1]) ++j;
+        const ssdn_wpack_args& w = t.e[j];
+        const long long off = i - t.w_off[j];
+        if (off < 0 || off >= (long long)w.M * w.cin * w.ntaps) continue;           // a bias (or a tensor without shadows)
+        const int tp = (int)(off % w.ntaps);
+        const int ci = (int)((off / w.ntaps) % w.cin);
+        const int mo = (int)(off / ((long long)w.ntaps * w.cin));
+        const int k = ci;                                                               // slot of input channel ci (k_to_cin is the identity on real slots)
+        ((h16*)w.wf)[((long long)tp * w.Mpad_f + mo) * w.Ktot + k] = (h16)pn;
+        if (w.wfc) ((h16*)w.wfc)[wpack_cm(tp, mo, k, w.Mpad_f, w.Ktot)] = (h16)pn;
+        if (w.wd && k < w.Mpad_d && mo < w.Kd) {       // (the data-gradient shadow may cover fewer input slots: decode_block_1.0's image channels need no gradient)
+            ((unsigned short*)w.wd)[((long long)tp * w.Mpad_d + k) * w.Kd + mo] = f2bf(pn);
+            if (w.wdc) ((unsigned short*)w.wdc)[wpack_cm(tp, k, mo, w.Mpad_d, w.Kd)] = f2bf(pn);
+        }
     }
+}
+// -> 1 if the run (adam, items[0..n)) can be fused: every layer's weights inside the Adam range, ascending, input-channel slots = channels
+int adam_pack_fusable(const ssdn_adam_args* a, const ssdn_wpack_args* const* items, int n) {
+    if (n < 1 || n > ADAM_PACK_MAX) return 0;
+    long long prev = -1;
+    for (int i = 0; i < n; ++i) {
+        const ssdn_wpack_args* w = items[i];
+        const long long off = w->w - a->p;
+        if (w->w < a->p || off + (long long)w->M * w->cin * w->ntaps > a->n || off <= prev) return 0;
+        if (w->c0 + w->c1_real != w->cin) return 0;
+        prev = off;
+    }
+    return 1;
+}
+int launch_adam_pack(const ssdn_adam_args* a, const ssdn_wpack_args* const* items, int n, hipStream_t s) {
+    AdamPackTable t;
+    t.a = *a;
+    t.n = n;
+    for (int i = 0; i < n; ++i) { t.e[i] = *items[i]; t.w_off[i] = items[i]->w - a->p; }
+    int g = ew_grid(a->n);
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(k_adam_pack, dim3(g), dim3(EW_BLOCK), 0, s, t);
+    return 0;
 }
 int launch_adam(const ssdn_adam_args* a, hipStream_t s) {
     int g = ew_grid(a->n);

@@ -58,6 +58,13 @@ class DevicePatchStream:
         self.generator.manual_seed(self.seed)
         self._calls = 0                    # Philox counter of SSDN_OP_NOISE: a fresh offset per minibatch
         self._static: Dict = {}            # metadata tensors that only depend on the batch shape
+        self._denoiser = None
+
+    def attach(self, denoiser):
+        """Write every noisy minibatch straight into `denoiser`'s training input buffer (Denoiser.input_buffer): the pipeline
+        then finds its input in place.  The yielded input tensor IS that buffer -- valid until the next minibatch is prepared."""
+        self._denoiser = denoiser
+        return self
 
     def __len__(self) -> int:
         return len(self.loader)
@@ -136,7 +143,13 @@ class DevicePatchStream:
         want_ref = algo in (NoiseAlgorithm.NOISE_TO_NOISE, NoiseAlgorithm.NOISE_TO_VOID)
         f32 = dict(dtype=torch.float32, device=dev)
         clean = torch.empty((B, Cn, H, W), **f32)
-        inp = torch.empty((B, Cn, H, W), **f32)
+        inp = None
+        if self._denoiser is not None and getattr(self._denoiser, "training", False):
+            buf = self._denoiser.input_buffer(B, H, W)
+            if tuple(buf.shape) == (B, Cn, H, W) and buf.device == dev:
+                inp = buf
+        if inp is None:
+            inp = torch.empty((B, Cn, H, W), **f32)
         ref = torch.empty((B, Cn, H, W), **f32) if want_ref else None
         par = torch.empty((B, Cn, 1, 1), **f32) if ranged else None
         par_ref = torch.empty((B, Cn, 1, 1), **f32) if (ranged and want_ref) else None

@@ -192,7 +192,13 @@ class Denoiser(nn.Module):
         them across calls.  (`train_step` uses the engine's buffers directly.)"""
         return self._run(data, clone=True)
 
-    def _run(self, data: List, clone: bool) -> Dict:
+    def input_buffer(self, B: int, H: int, W: int) -> Tensor:
+        """The fp32 [B, C, H, W] input buffer of the TRAINING engine for this shape.  A producer that writes the noisy minibatch
+        straight into it (ssdn.datasets.DevicePatchStream does, when attached) and passes that very tensor as the pipeline
+        input saves `run_pipeline` its device-to-device copy; the buffer is overwritten by the next minibatch."""
+        return self._engine(B, H, W, True).inp
+
+    def _run(self, data: List, clone: bool, bridge: bool = True) -> Dict:
         if self._pipeline not in (Pipeline.MSE, Pipeline.SSDN, Pipeline.MASK_MSE):
             raise NotImplementedError("Unsupported processing pipeline")
         inp = data[NoisyDataset.INPUT]
@@ -207,11 +213,17 @@ class Denoiser(nn.Module):
                 raise IndexError("mask coordinates out of range for a %dx%d image" % (H, W))
         train = self.training and torch.is_grad_enabled()
         eng = self._engine(B, H, W, train, ncoords=(coords.shape[1] if coords is not None else 64))
-        eng.inp.copy_(inp.to(torch.float32), non_blocking=True)          # device boundary (denoiser.py:143,186)
+        if inp.data_ptr() != eng.inp.data_ptr():                          # (a producer may have written the engine's buffer itself)
+            eng.inp.copy_(inp.to(torch.float32), non_blocking=True)      # device boundary (denoiser.py:143,186)
         have_loss = True
         if self._pipeline == Pipeline.SSDN:
             if self.cfg[ConfigValue.NOISE_VALUE] == NoiseValue.KNOWN:
-                eng.noise_param.copy_(meta[MD.INPUT_NOISE_VALUES].reshape(B).to(torch.float32), non_blocking=True)
+                npv = meta[MD.INPUT_NOISE_VALUES]
+                # the same (device) parameter tensor as in the previous step, unmodified: nothing to upload again
+                tag = (npv.data_ptr(), npv._version, tuple(npv.shape)) if npv.device == eng.noise_param.device else None
+                if tag is None or getattr(eng, "_np_tag", None) != tag:
+                    eng.noise_param.copy_(npv.reshape(B).to(torch.float32), non_blocking=True)
+                    eng._np_tag = tag
         else:
             have_loss = ref is not None and (self._pipeline == Pipeline.MSE or coords is not None)
             if have_loss:
@@ -244,7 +256,8 @@ class Denoiser(nn.Module):
         if have_loss:
             loss = eng.loss
             # (_LossBridge.forward clones; the eval branch clones here)
-            out[PipelineOutput.LOSS] = _LossBridge.apply(self._anchor, self, eng, loss) if train else own(loss)
+            # (train_step drives the backward list itself: no autograd bridge, no copy of the loss)
+            out[PipelineOutput.LOSS] = (_LossBridge.apply(self._anchor, self, eng, loss) if bridge else loss) if train else own(loss)
         return out
 
     def backward(self):
@@ -297,7 +310,7 @@ class Denoiser(nn.Module):
         for data parallelism -- the per-bucket all-reduces are issued behind events recorded inside the backward list, so
         they overlap the rest of the backward pass; Adam waits for them and folds in 1 / world."""
         from ssdn.hip import dp
-        out = self._run(data, clone=False)
+        out = self._run(data, clone=False, bridge=False)
         eng = self._last_train_engine
         scale = dp.exchange_step(lambda ex: eng.backward(exchange=ex), self.flat_grad, exchange)
         self.optimizer_step(lr, scale)

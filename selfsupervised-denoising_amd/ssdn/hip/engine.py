@@ -347,9 +347,19 @@ class DenoiserEngine:
         return recs
 
     def _opt_ops(self):
-        self._adam_args = L.AdamArgs(_ptr(self.params), _ptr(self.grads), _ptr(self.m), _ptr(self.v), self.params.numel(),
-                                     0.0, 0.9, 0.99, 1e-8, 1.0, 1.0, 1.0)
-        return [("adam", self._adam_args)]
+        """Fused Adam over the flat buffer, each range directly followed by the re-packs of the layers inside it: the executor
+        runs such a run as ONE launch (k_adam_pack: the thread that updates a weight also writes its fp16 / bf16 shadows)."""
+        def adam(lo, hi):
+            return L.AdamArgs(_ptr(self.params, 4 * lo), _ptr(self.grads, 4 * lo), _ptr(self.m, 4 * lo), _ptr(self.v, 4 * lo), hi - lo,
+                              0.0, 0.9, 0.99, 1e-8, 1.0, 1.0, 1.0)
+        n_tot = self.params.numel()
+        n_main = self.sigma.plan.param_base if self.sigma is not None else n_tot
+        self._adam_args = [adam(0, n_main)]
+        recs = [("adam", self._adam_args[0])] + [self.main._mat(op) for op in self.main.plan.pack]
+        if self.sigma is not None:
+            self._adam_args.append(adam(n_main, n_tot))
+            recs += [("adam", self._adam_args[1])] + [self.sigma._mat(op) for op in self.sigma.plan.pack]
+        return recs
 
     # ---- execution -----------------------------------------------------------------------------------------
     def repack(self, stream=None):
@@ -389,8 +399,7 @@ class DenoiserEngine:
             self.sigma.bwd.run(s)
 
     def adam(self, lr: float, step: int, gscale: float = 1.0, stream=None):
-        a = self._adam_args
-        a.lr, a.bc1, a.bc2, a.gscale = lr, 1.0 - 0.9 ** step, 1.0 - 0.99 ** step, gscale
+        for a in self._adam_args:
+            a.lr, a.bc1, a.bc2, a.gscale = lr, 1.0 - 0.9 ** step, 1.0 - 0.99 ** step, gscale
         s = current_stream() if stream is None else stream
-        self.ops_opt.run(s)
-        self.repack(s)
+        self.ops_opt.run(s)                   # optimiser step + re-pack of the MFMA shadows (one launch per network)

@@ -458,6 +458,8 @@ class DenoiserTrainer:
             dev = self.denoiser.device if self.denoiser is not None and hasattr(self.denoiser, "device") else \
                 torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
             loader = DevicePatchStream(loader, dataset, dev, rank=self.rank)
+            if self.denoiser is not None and self.denoiser.device.type == "cuda":
+                loader.attach(self.denoiser)
         return loader, dataset, sampler
 
     def set_train_data(self, path: str):

@@ -344,3 +344,42 @@ def test_gradient_agreement_structured_images():
     assert not worst, worst
     n = d._n_main
     assert float(((gd[:n] > 0) == (gr[:n] > 0)).float().mean()) >= 0.99
+
+
+@pytest.mark.parametrize("alg,style,mode", [("ssdn", "gauss25", "known"), ("ssdn", "gauss25", "var"), ("ssdn", "poisson30", "const"), ("n2v", "gauss25", "known")])
+def test_fused_adam_repack_is_bit_identical_to_adam_then_wpack(alg, style, mode):
+    """The optimiser list is [SSDN_OP_ADAM, SSDN_OP_WPACK x layers] per network; the executor runs it as ONE launch (k_adam_pack: the
+    thread that updates a weight writes its fp16 / bf16 shadows).  The parameters, the moments and EVERY shadow (forward, data
+    gradient, and their chunk-major copies) must equal, bit for bit, what the plain Adam launch followed by the re-pack produces."""
+    import ctypes as C
+    from ssdn.hip import lib as L
+    from ssdn.hip.engine import OpList, current_stream
+    d = make_denoiser(alg, style, mode, 3)
+    d.train()
+    eng = d._engine(2, 32, 32, True)
+    g = torch.Generator().manual_seed(3)
+    d.flat_grad.copy_(torch.randn(d.flat.numel(), generator=g) * 1e-3)
+    start = [t.clone() for t in (d.flat, d.adam_m, d.adam_v)]
+    nets = [eng.main] + ([eng.sigma] if eng.sigma is not None else [])
+    shadow_names = [(net, k) for net in nets for k in net.t if any(k.startswith(net.plan.prefix + s) for s in ("wf/", "wd/", "wfc/", "wdc/"))]
+    assert len(shadow_names) >= 20 * len(nets)
+
+    # fused: the engine's own optimiser list
+    eng.adam(3e-4, 1, 0.5)
+    torch.cuda.synchronize()
+    fused = [t.clone() for t in (d.flat, d.adam_m, d.adam_v)] + [net.t[k].clone() for net, k in shadow_names]
+    # reference: the same start, plain SSDN_OP_ADAM over the whole buffer (alone in its list: nothing to fuse), then the re-pack lists
+    for t, s0 in zip((d.flat, d.adam_m, d.adam_v), start):
+        t.copy_(s0)
+    for net, k in shadow_names:
+        net.t[k].fill_(0)
+    a = L.AdamArgs(d.flat.data_ptr(), d.flat_grad.data_ptr(), d.adam_m.data_ptr(), d.adam_v.data_ptr(), d.flat.numel(),
+                   3e-4, 0.9, 0.99, 1e-8, 1.0 - 0.9, 1.0 - 0.99, 0.5)
+    OpList([("adam", a)]).run(current_stream())
+    eng.repack()
+    torch.cuda.synchronize()
+    plain = [t.clone() for t in (d.flat, d.adam_m, d.adam_v)] + [net.t[k].clone() for net, k in shadow_names]
+    names = ["params", "m", "v"] + [k for _, k in shadow_names]
+    for nm, x, y in zip(names, fused, plain):
+        assert torch.equal(x.view(torch.uint8) if x.dtype not in (torch.float32,) else x, y.view(torch.uint8) if y.dtype not in (torch.float32,) else y), nm
+    assert not torch.equal(fused[0], start[0])                    # (the step did move the parameters)
