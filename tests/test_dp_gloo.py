@@ -135,3 +135,25 @@ def test_bucket_ranges_cover_flat_buffer_in_backward_order():
     assert r[0][1] == n and r[-1] == (n, n + 1) and r[2][0] == 0
     covered = sorted(r)
     assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
+
+
+def test_gradient_buckets_of_the_benchmark_network():
+    """the flat gradient of the blind-spot RGB network (BASELINE configs 2 / 3) is exchanged in <= 4 contiguous
+    buckets, in the order the backward pass completes them -- head + decode_block_1 | decode_block_2..5 | encoder | sigma
+    estimator -- which tile the whole buffer exactly once; sizes 1.42 / 3.15 / 0.50 / 4.41 MB."""
+    layers = net_layers(3, 9, True)
+    n_main = net_param_count(layers)
+    n_sig = net_param_count(net_layers(3, 1, False))
+    assert (n_main, n_sig) == (1269129, 1102177)
+    r = dp.bucket_ranges(layers, n_main, n_main + n_sig)
+    assert r == [(914784, 1269129), (126048, 914784), (0, 126048), (1269129, 2371306)]
+    assert sorted(r)[0][0] == 0 and all(a[1] == b[0] for a, b in zip(sorted(r), sorted(r)[1:])) and sorted(r)[-1][1] == n_main + n_sig
+    assert [round((hi - lo) * 4 / 1e6, 2) for lo, hi in r] == [1.42, 3.15, 0.50, 4.41]
+    assert len(dp.bucket_ranges(layers, n_main, n_main)) == 3            # no sigma estimator: three buckets
+    names = dp.bucket_layers(layers)
+    assert {"output_block.0", "output_block.2", "output_block.4", "decode_block_1.0", "decode_block_1.2"} == names[0]
+    assert all(n.startswith("decode_block_") for n in names[1]) and len(names[1]) == 8
+    assert all(n.startswith("encode_block_") for n in names[2]) and len(names[2]) == 7
+    off = {l.name: l.w_off for l in layers}
+    for k, b in enumerate(names):                                          # a bucket's layers are exactly its range of the buffer
+        assert all(r[k][0] <= off[n] < r[k][1] for n in b)
