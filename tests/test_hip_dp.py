@@ -129,3 +129,27 @@ def test_two_rank_train_step_equals_single_process():
     cos_o = float((upd_o * upd_g).sum() / (np.linalg.norm(upd_o) * np.linalg.norm(upd_g) + 1e-30))
     print("2-rank update vs oracle full-batch update: cosine %.5f (vs single-process HIP run %.5f)" % (cos_o, cos))
     assert cos_o >= 0.99, cos_o          # measured 0.9957 (deterministic: identical in repeated runs)
+
+
+def test_bench_two_ranks_on_one_gpu_over_gloo():
+    """`python bench.py --gpus 2` launched plainly (no torchrun environment) on the 1-GPU test box: the script spawns its own two ranks;
+    with SSDN_BENCH_BACKEND=gloo they share the GPU and exchange device tensors through gloo -- every line of the N-rank bench path
+    (sharded minibatches, bucketed exchange behind the backward pass, barrier + max-over-ranks timing, one JSON line) runs on the
+    device.  Without the override RCCL refuses two ranks on one device and the launcher must report that as ONE JSON error line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2", "--no-cpu-baseline"],
+                       env=dict(env, SSDN_BENCH_BACKEND="gloo"), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(lines) == 1, p.stderr[-2000:]
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["global_batch"] == 64 and r["config"]["backend"] == "gloo" and r["value"] > 0
+    assert r["roofline"]["launches"] > 0 and "stub" not in r
+    if torch.cuda.device_count() == 1:
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                           env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        assert p.returncode != 0 and len(lines) == 1 and "error" in json.loads(lines[0]), p.stdout[-2000:]
