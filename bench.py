@@ -261,8 +261,8 @@ def run_rank(args):
     # roofline leg: HIP events around the launches of the dominant kernel, k_cdma<3,*> (the 96-output-channel 3x3 layers at
     # 32x32 and 64x64 pixels, forward and data-gradient roles: 8 launches per step, 60 % of the step's flops), on the launch
     # stream, during the timed steps.  An event pair costs ~10 us of stream time (it serialises what would be back-to-back
-    # kernels), so only every 5th launch is bracketed -> the sample rotates over all eight layers.
-    PROF_STRIDE = 5
+    # kernels), so only every 9th launch is bracketed (9 is coprime to the 8 launches of a step: the sample rotates over all eight layers).
+    PROF_STRIDE = 9
     if lib is not None:
         prof_kind = L.PROF["cdma_mt3"]
         lib.ssdn_profile_enable(prof_kind, 64 * args.steps // PROF_STRIDE + 64)
