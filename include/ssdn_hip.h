@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define SSDN_ABI_VERSION 6
+#define SSDN_ABI_VERSION 7
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -451,6 +451,16 @@ int ssdn_conv_fuses_pool(const ssdn_conv_args* a);
 int ssdn_conv_fuses_upsum(const ssdn_conv_args* a);
 /* 1 if SSDN_OP_CONV with these arguments applies the fused SSDN_OP_UNROT_BWD (ssdn_conv_args.unrot), 0 if it cannot. */
 int ssdn_conv_fuses_unrot(const ssdn_conv_args* a);
+
+/* ssdn_run_ops executes a run of consecutive SSDN_OP_CONV ops on one lane as ONE launch (k_conv_chain, csrc/conv_chain.hip: one
+ * workgroup per image walks all layers with the activations resident in LDS) when the run is a "chain": forward role (bf16 = 0),
+ * 3x3 layers with identical taps and N, power-of-two images of at most 64 pixels, kc = 48 with c0, c1 multiples of 48,
+ * bias + LeakyReLU, 16-bit output, no mask / add / upsum / unrot; a source is either the dst / pool view of an earlier layer of
+ * the run (same p, cs, co, matching shape) or a tensor no layer of the run writes; every dst and pool is still written to HBM.
+ * The result is bit-identical to one launch per op.  ssdn_conv_chain_len returns how many ops of the prefix of items[0..n) run as
+ * one launch (0 = none, else >= 2; at most 8); ssdn_conv_set_chain(0) switches the merging off (test aid), (1) on (default). */
+int ssdn_conv_chain_len(const ssdn_conv_args* const* items, int n);
+int ssdn_conv_set_chain(int on);
 
 /* ssdn_run_ops executes a run of consecutive SSDN_OP_WGRAD ops on one lane as ONE launch (k_wgrad_multi) when every op of the
  * run is "mergeable": at most 32768 pixels (the layers at the bottom of the U), mblocks <= 1, and a tiling the merged kernel

@@ -117,6 +117,11 @@ int launch_adam_pack(const ssdn_adam_args* a, const ssdn_wpack_args* const* item
 int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s);
 int launch_noise(const ssdn_noise_args* a, hipStream_t s);
 int conv_lds_bytes(const ssdn_conv_args* a);
+int conv_validate(const ssdn_conv_args* a);                     // conv_mfma.hip: argument checks shared by every conv launcher
+// conv_chain.hip: a run of consecutive small 3x3 forward layers (images of <= 64 pixels) as ONE launch, activations resident in LDS
+#define CONV_CHAIN_MAX 8
+int conv_chain_len(const ssdn_conv_args* const* items, int n);   // layers of the prefix that runs as one launch (0 or >= 2)
+int launch_conv_chain(const ssdn_conv_args* const* items, int n, hipStream_t s);
 // conv_dma.hip: persistent LDS-DMA convolution for the 3x3 layers that carry the flops
 bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size);
 int conv_dma_lds_bytes(int mt);

@@ -786,7 +786,7 @@ extern "C" int ssdn_conv_set_mode(int mode) {
 static bool conv_use_dma(const ssdn_conv_args* a) { return g_conv_mode > 0 && !a->pool.p && conv_dma_eligible(a, g_conv_mode == 2); }
 static bool conv_use_gemm(const ssdn_conv_args* a) { return g_conv_mode > 0 && gemm_dma_eligible(a); }
 
-static int conv_validate(const ssdn_conv_args* a) {
+int conv_validate(const ssdn_conv_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("conv: ntaps out of range");
     if (a->ltw + a->lth + a->ltn > 9 || a->ltw < 0 || a->lth < 0 || a->ltn < 0) return ssdn_set_error("conv: tile must have <= 512 pixels");
     if (a->Ktot != a->c0 + a->c1 || (a->Ktot & 15)) return ssdn_set_error("conv: Ktot must equal c0+c1 and be a multiple of 16");

@@ -126,12 +126,13 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
                  mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 6      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 7      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
-           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot"]
+           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_conv_chain_len",
+           "ssdn_conv_set_chain"]
 PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6)
 
 _lib = None
@@ -171,6 +172,10 @@ def load() -> C.CDLL:
     lib.ssdn_profile_read.restype = C.c_int
     lib.ssdn_conv_set_mode.argtypes = [C.c_int]
     lib.ssdn_conv_set_mode.restype = C.c_int
+    lib.ssdn_conv_set_chain.argtypes = [C.c_int]
+    lib.ssdn_conv_set_chain.restype = C.c_int
+    lib.ssdn_conv_chain_len.argtypes = [C.POINTER(C.c_void_p), C.c_int]
+    lib.ssdn_conv_chain_len.restype = C.c_int
     lib.ssdn_conv_fuses_unrot.argtypes = [C.c_void_p]
     lib.ssdn_conv_fuses_unrot.restype = C.c_int
     lib.ssdn_conv_fuses_upsum.argtypes = [C.c_void_p]

@@ -443,3 +443,58 @@ def test_merged_weight_gradient_launch_is_bit_identical():
     n = plan.nparams
     assert torch.isfinite(one_by_one[:n]).all()
     assert torch.equal(one_by_one[:n], merged[:n])
+
+
+@pytest.fixture
+def conv_chain_reset():
+    yield
+    from ssdn.hip import lib as L
+    L.load().ssdn_conv_set_chain(1)
+
+
+# (cin, cout, blindspot, B, P, layers the chain must cover): 4 x B images; the chain starts at the first layer whose images have
+# <= 64 pixels and whose max-pool the planner fused into the conv (whole-image tiles: N a multiple of 256 / pixels per image)
+@pytest.mark.parametrize("cin,cout,bs,B,P,min_chain", [(3, 9, True, 4, 64, 7), (3, 9, True, 8, 32, 2), (3, 3, False, 16, 64, 7), (1, 2, True, 32, 64, 7)])
+def test_conv_chain_is_bit_identical(cin, cout, bs, B, P, min_chain, conv_chain_reset):
+    """A run of consecutive small forward layers executes as ONE launch with the activations resident in LDS (k_conv_chain,
+    csrc/conv_chain.hip); every tensor the separate launches would have written -- each layer's output and each fused max-pool
+    output -- must come out bit for bit the same."""
+    import ctypes as C
+    from ssdn.hip import lib as L
+    from ssdn.hip.engine import DeviceNet, OpList, current_stream
+    from ssdn.hip.graph import NetPlan
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=lib.ssdn_device_cus())
+    g = torch.Generator(device="cpu").manual_seed(5)
+    flat = (torch.randn(plan.nparams, generator=g) * 0.08).to(dev)
+    dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+    dn.t["m/in32"].copy_(torch.rand(dn.t["m/in32"].shape, generator=g).to(dev))
+    dn.pack.run(current_stream())
+    recs = [dn._mat(op) for op in plan.fwd]
+    # the longest chain the library finds in the forward list
+    best = 0
+    for i, op in enumerate(plan.fwd):
+        run = []
+        while i + len(run) < len(plan.fwd) and plan.fwd[i + len(run)].type == "conv" and len(run) < 8:
+            run.append(recs[i + len(run)])
+        if len(run) > 1:
+            arr = (C.c_void_p * len(run))(*[C.addressof(r[1]) for r in run])
+            best = max(best, lib.ssdn_conv_chain_len(arr, len(run)))
+    assert best >= min_chain, "the fixture must exercise the chained launch (longest chain: %d layers)" % best
+
+    def run_fwd(chain):
+        L.check(lib.ssdn_conv_set_chain(int(chain)))
+        for name, t in dn.t.items():
+            if t.dtype == torch.float16 and "/w" not in name:
+                t.fill_(float("nan"))
+        OpList(recs).run(current_stream())
+        torch.cuda.synchronize()
+        return {name: t.clone() for name, t in dn.t.items() if t.dtype in (torch.float16, torch.float32) and "/w" not in name}
+
+    separate = run_fwd(False)
+    chained = run_fwd(True)
+    assert torch.isfinite(separate["m/out32"]).all()
+    bad = [name for name in separate if not torch.equal(separate[name].view(torch.int16 if separate[name].dtype == torch.float16 else torch.int32),
+                                                        chained[name].view(torch.int16 if chained[name].dtype == torch.float16 else torch.int32))]
+    assert not bad, "tensors that differ between the chained and the separate launches: %s" % bad
