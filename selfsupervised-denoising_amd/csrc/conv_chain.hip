@@ -25,6 +25,12 @@
 #define CH_MAX_PLANES 14
 #define CH_MAX_LOADS 4
 #define CH_THREADS 256
+extern "C" void* ssdn_debug_get_trace();
+#ifdef SSDN_TUNING
+#define CH_ABL(c, bit) (((c).ablate & (bit)) != 0)
+#else
+#define CH_ABL(c, bit) false
+#endif
 
 struct ChPlane { int off, str, roww, org, lw, lh, C; };   // LDS byte offset, pixel stride (B), pixels per halo row, byte offset of pixel (0,0)
 struct ChLoad { ssdn_view src; int plane; int pad_; };
@@ -33,11 +39,15 @@ struct ChLayer {
     const float* bias;
     ssdn_view dst, pool;
     int M, Mpad, Ktot, c0, up0;
-    int p0, p1, pd, pp, pool_shifted;
+    int pool_shifted, has_pool;
+    unsigned npc_magic;            // magic reciprocal of M / 8 (16-byte pieces per pixel): exact e / npc for e * npc < 2^32
+    ChPlane P0, P1, PD, PP;        // source planes (channels [0, c0) / the rest), output plane, pooled plane
 };
 struct ChainArgs {
     int N, nloads, nlayers, lds_bytes;
-    int dy[9], dx[9];
+    int ablate;       // tuning aid (SSDN_CHAIN_ABLATE, -DSSDN_TUNING builds): 1 no MFMA loop, 2 no HBM stores, 4 no pool, 8 no weight stream
+    unsigned long long* trace;   // tuning aid (ssdn_debug_set_trace, -DSSDN_TUNING builds): 64 s_memtime stamps per workgroup, or NULL
+    unsigned tap_dy, tap_dx;     // the nine tap offsets + 4, three bits each (SGPR constants: an s_load in the K loop would drain the LDS queue)
     ChPlane pl[CH_MAX_PLANES];
     ChLoad ld[CH_MAX_LOADS];
     ChLayer ly[CH_MAX_LAYERS];
@@ -57,11 +67,21 @@ static __device__ __forceinline__ void chain_issue_w(half8 (&wr)[27], const h16*
         for (int ks = 0; ks < 3; ++ks) wr[t * 3 + ks] = ld_h8(lanep + (long long)t * tapstride + ks * 16);
 }
 
-template <int NPT>
+static __device__ __forceinline__ unsigned ch_div(unsigned x, unsigned magic) { return magic ? __umulhi(x, magic) : x; }
+
+template <int NPT, typename STAMP>
 static __device__ __forceinline__ void chain_layer(const ChainArgs& c, const ChLayer& L, char* smem, int mt, int l31, int kh,
-                                                   half8 (&wr)[27], const h16* next_lanep, int next_tapstride) {
-    const ChPlane P0 = c.pl[L.p0 >= 0 ? L.p0 : L.p1], P1 = c.pl[L.p1 >= 0 ? L.p1 : L.p0], PD = c.pl[L.pd];
+                                                   half8 (&wr)[27], const h16* next_lanep, int next_tapstride, STAMP stamp) {
+    const ChPlane P0 = L.P0, P1 = L.P1, PD = L.PD;
     const int HWp = 1 << (PD.lw + PD.lh);
+    // bias of this lane's 16 output rows: on its way while the K loop runs
+    float bb[4][4];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+        const int m0 = mt * 32 + gq * 8 + kh * 4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) bb[gq][j] = L.bias[m0 < L.M ? m0 + j : 0];
+    }
     int py[NPT], px[NPT];
 #pragma unroll
     for (int p = 0; p < NPT; ++p) {
@@ -78,7 +98,7 @@ static __device__ __forceinline__ void chain_layer(const ChainArgs& c, const ChL
     const int nch = L.Ktot / 48;
     const int tapstride = L.Mpad * L.Ktot;
     const h16* lanep = L.w + (long long)(mt * 32 + l31) * L.Ktot + kh * 8;
-    for (int ch = 0; ch < nch; ++ch) {
+    for (int ch = 0; ch < nch && !CH_ABL(c, 1); ++ch) {
         const int k0 = ch * 48;
         const bool from0 = k0 < L.c0;
         const int sh = from0 ? L.up0 : 0;
@@ -88,38 +108,47 @@ static __device__ __forceinline__ void chain_layer(const ChainArgs& c, const ChL
         // address: the last chunk of the chain re-loads itself -- unconditional loads keep the compiler's vmcnt accounting exact)
         const h16* np = ch + 1 < nch ? lanep + (ch + 1) * 48 : next_lanep;
         const int nts = ch + 1 < nch ? tapstride : next_tapstride;
+        int boff[9][NPT];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            int boff[NPT];
+            const int dy = (int)((c.tap_dy >> (3 * t)) & 7u) - 4, dx = (int)((c.tap_dx >> (3 * t)) & 7u) - 4;
 #pragma unroll
             for (int p = 0; p < NPT; ++p)
-                boff[p] = cbase + (((py[p] + c.dy[t]) >> sh) * roww + ((px[p] + c.dx[t]) >> sh)) * str;
-#pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                const half8 a = wr[t * 3 + ks];
-                wr[t * 3 + ks] = ld_h8(np + (long long)t * nts + ks * 16);
-#pragma unroll
-                for (int p = 0; p < NPT; ++p) {
-                    const half8 b = *reinterpret_cast<const half8*>(smem + boff[p] + ks * 32);
-                    acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc[p], 0, 0, 0);
-                }
-            }
+                boff[t][p] = cbase + (((py[p] + dy) >> sh) * roww + ((px[p] + dx) >> sh)) * str;
         }
+        // B fragments are read CH_BD K-steps ahead of the MFMA that consumes them (one wave per SIMD: nothing else hides the LDS latency)
+        constexpr int BD = 4;
+        half8 bq[BD][NPT];
+        auto rd = [&](int s, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) bq[slot][p] = *reinterpret_cast<const half8*>(smem + boff[s / 3][p] + (s % 3) * 32);
+        };
+        __builtin_amdgcn_sched_barrier(0);                     // (the tap offsets above are computed before the pipeline starts)
+#pragma unroll
+        for (int s = 0; s < BD; ++s) rd(s, s);
+        stamp();
+#pragma unroll
+        for (int s = 0; s < 27; ++s) {
+            const half8 a = wr[s];
+            if (!CH_ABL(c, 8)) wr[s] = ld_h8(np + (long long)(s / 3) * nts + (s % 3) * 16);
+#pragma unroll
+            for (int p = 0; p < NPT; ++p) acc[p] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, bq[s % BD][p], acc[p], 0, 0, 0);
+            if (s + BD < 27) rd(s + BD, s % BD);
+            __builtin_amdgcn_sched_barrier(0);                 // pin the step: left alone, the scheduler sinks every read to its MFMA
+        }
+        stamp();
     }
     // epilogue: bias + LeakyReLU -> fp16 -> the output plane (rows >= M of a padded tile are not stored)
 #pragma unroll
     for (int gq = 0; gq < 4; ++gq) {
         const int m0 = mt * 32 + gq * 8 + kh * 4;
         if (m0 >= L.M) continue;
-        float bb[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) bb[j] = L.bias[m0 + j];
 #pragma unroll
         for (int p = 0; p < NPT; ++p) {
             if (p * 32 + l31 >= HWp) continue;
             float v[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = lrelu(acc[p][gq * 4 + j] + bb[j]);
+            for (int j = 0; j < 4; ++j) v[j] = lrelu(acc[p][gq * 4 + j] + bb[gq][j]);
             u32x2_t o;
             o[0] = pack_f16x2(v[0], v[1]);
             o[1] = pack_f16x2(v[2], v[3]);
@@ -133,6 +162,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs c) {
     const int n = blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    [[maybe_unused]] int tr_i = 0;
+    auto stamp = [&]() {
+#ifdef SSDN_TUNING
+        if (c.trace && tid == 0 && tr_i < 64) c.trace[(size_t)blockIdx.x * 64 + tr_i++] = __builtin_amdgcn_s_memtime();
+#endif
+    };
+    stamp();
     half8 wr[27];
     // weights of the first layer this wave works on: in flight while the planes are zeroed and the inputs arrive
     auto lanep_of = [&](int li) { return c.ly[li].w + (long long)(wave * 32 + l31) * c.ly[li].Ktot + kh * 8; };
@@ -159,17 +195,20 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs c) {
         }
     }
     lds_barrier();
+    stamp();
     for (int li = 0; li < c.nlayers; ++li) {
         const ChLayer& L = c.ly[li];
-        const ChPlane PD = c.pl[L.pd];
+        const ChPlane PD = L.PD;
         if (active(li)) {
             const int nx = next_active(li);
             const h16* nlp = nx >= 0 ? lanep_of(nx) : lanep_of(li) + (L.Ktot - 48);
             const int nts = nx >= 0 ? c.ly[nx].Mpad * c.ly[nx].Ktot : L.Mpad * L.Ktot;
-            if (PD.lw + PD.lh > 5) chain_layer<2>(c, L, smem, wave, l31, kh, wr, nlp, nts);
-            else chain_layer<1>(c, L, smem, wave, l31, kh, wr, nlp, nts);
+            if (PD.lw + PD.lh > 5) chain_layer<2>(c, L, smem, wave, l31, kh, wr, nlp, nts, stamp);
+            else chain_layer<1>(c, L, smem, wave, l31, kh, wr, nlp, nts, stamp);
         }                                                      // (an idle wave keeps the chunk it holds for its next layer)
+        stamp();
         lds_barrier();
+        stamp();
         // ---- the output plane -> HBM (16-byte pieces of consecutive pixels), and the fused Shift2d + MaxPool2d ----
         const int lhw = PD.lw + PD.lh;
         const int npc = L.M >> 3;
@@ -177,17 +216,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs c) {
             const int total = npc << lhw;
             h16* dst = (h16*)L.dst.p + L.dst.co;
             for (int e = tid; e < total; e += CH_THREADS) {
-                const int q = e / npc, cc = e - q * npc;
+                const int q = ch_div(e, L.npc_magic), cc = e - q * npc;
                 const u32x4_t v = *reinterpret_cast<const u32x4_t*>(smem + PD.off + PD.org + ((q >> PD.lw) * PD.roww + (q & ((1 << PD.lw) - 1))) * PD.str + cc * 16);
-                *reinterpret_cast<u32x4_t*>(dst + ((long long)(n << lhw) + q) * L.dst.cs + cc * 8) = v;
+                if (!CH_ABL(c, 2)) *reinterpret_cast<u32x4_t*>(dst + ((long long)(n << lhw) + q) * L.dst.cs + cc * 8) = v;
             }
         }
-        if (L.pp >= 0) {
-            const ChPlane PP = c.pl[L.pp];
+        stamp();
+        if (L.has_pool && !CH_ABL(c, 4)) {
+            const ChPlane PP = L.PP;
             const int total = npc << (lhw - 2);
             h16* dst = (h16*)L.pool.p + L.pool.co;
             for (int e = tid; e < total; e += CH_THREADS) {
-                const int pq = e / npc, cc = e - pq * npc;
+                const int pq = ch_div(e, L.npc_magic), cc = e - pq * npc;
                 const int pj = pq & ((1 << PP.lw) - 1), pi = pq >> PP.lw;
                 const int r0 = L.pool_shifted ? 2 * pi - 1 : 2 * pi;
                 u32x4_t best;
@@ -207,10 +247,11 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(ChainArgs c) {
                     }
                 }
                 *reinterpret_cast<u32x4_t*>(smem + PP.off + PP.org + (pi * PP.roww + pj) * PP.str + cc * 16) = best;
-                *reinterpret_cast<u32x4_t*>(dst + ((long long)(n << (lhw - 2)) + pq) * L.pool.cs + cc * 8) = best;
+                if (!CH_ABL(c, 2)) *reinterpret_cast<u32x4_t*>(dst + ((long long)(n << (lhw - 2)) + pq) * L.pool.cs + cc * 8) = best;
             }
             lds_barrier();
         }
+        stamp();
     }
 }
 
@@ -289,7 +330,9 @@ static int chain_plan(const ssdn_conv_args* const* items, int n, ChainArgs* out)
     if (!chain_layer_ok(f, f)) return 0;
     int mny = 0, mxy = 0, mnx = 0, mxx = 0;
     for (int t = 0; t < 9; ++t) {
-        b.c.dy[t] = f->dy[t]; b.c.dx[t] = f->dx[t];
+        if (f->dy[t] < -4 || f->dy[t] > 3 || f->dx[t] < -4 || f->dx[t] > 3) return 0;
+        b.c.tap_dy |= (unsigned)(f->dy[t] + 4) << (3 * t);
+        b.c.tap_dx |= (unsigned)(f->dx[t] + 4) << (3 * t);
         mny = f->dy[t] < mny ? f->dy[t] : mny; mxy = f->dy[t] > mxy ? f->dy[t] : mxy;
         mnx = f->dx[t] < mnx ? f->dx[t] : mnx; mxx = f->dx[t] > mxx ? f->dx[t] : mxx;
     }
@@ -303,15 +346,24 @@ static int chain_plan(const ssdn_conv_args* const* items, int n, ChainArgs* out)
         ChLayer& L = b.c.ly[i];
         L.w = (const h16*)a->w; L.bias = a->bias; L.dst = a->dst; L.pool = a->pool;
         L.M = a->M; L.Mpad = a->Mpad; L.Ktot = a->Ktot; L.c0 = a->c0; L.up0 = a->up0; L.pool_shifted = a->pool_shifted;
-        L.p0 = L.p1 = L.pp = -1;
+        int p0 = -1, p1 = -1, pd = -1, pp = -1;
         bool ok = true;
-        if (a->c0 > 0) { L.p0 = chain_source(b, a->src0, a->up0 ? a->H / 2 : a->H, a->up0 ? a->W / 2 : a->W, a->c0); ok = ok && L.p0 >= 0; }
-        if (ok && a->c1 > 0) { L.p1 = chain_source(b, a->src1, a->H, a->W, a->c1); ok = ok && L.p1 >= 0; }
+        if (a->c0 > 0) { p0 = chain_source(b, a->src0, a->up0 ? a->H / 2 : a->H, a->up0 ? a->W / 2 : a->W, a->c0); ok = ok && p0 >= 0; }
+        if (ok && a->c1 > 0) { p1 = chain_source(b, a->src1, a->H, a->W, a->c1); ok = ok && p1 >= 0; }
         // an output tensor that is already mirrored by a plane (written twice, or written after it was loaded) is not a chain
         for (int j = 0; ok && j < b.nplanes; ++j)
             if (b.pv[j].p == a->dst.p || (a->pool.p && b.pv[j].p == a->pool.p)) ok = false;
-        if (ok) { L.pd = chain_add_plane(b, a->dst, a->H, a->W, a->M, true); ok = L.pd >= 0; }
-        if (ok && a->pool.p) { L.pp = chain_add_plane(b, a->pool, a->H / 2, a->W / 2, a->M, true); ok = L.pp >= 0; }
+        if (ok) { pd = chain_add_plane(b, a->dst, a->H, a->W, a->M, true); ok = pd >= 0; }
+        if (ok && a->pool.p) { pp = chain_add_plane(b, a->pool, a->H / 2, a->W / 2, a->M, true); ok = pp >= 0; }
+        if (ok) {
+            L.P0 = b.c.pl[p0 >= 0 ? p0 : p1];
+            L.P1 = b.c.pl[p1 >= 0 ? p1 : p0];
+            L.PD = b.c.pl[pd];
+            L.has_pool = pp >= 0;
+            L.PP = b.c.pl[pp >= 0 ? pp : pd];
+            const unsigned npc = (unsigned)a->M / 8;
+            L.npc_magic = npc <= 1 ? 0u : (unsigned)((0x100000000ull + npc - 1) / npc);
+        }
         if (!ok || b.c.lds_bytes > 160 * 1024) { b = save; break; }
         accepted = i + 1;
     }
@@ -337,6 +389,9 @@ int launch_conv_chain(const ssdn_conv_args* const* items, int n, hipStream_t s) 
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_chain, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
+    static const int env_ablate = [] { const char* e = ssdn_tuning_env("SSDN_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
+    c.ablate = env_ablate;
+    c.trace = (unsigned long long*)ssdn_debug_get_trace();
     hipLaunchKernelGGL(k_conv_chain, dim3(c.N), dim3(CH_THREADS), c.lds_bytes, s, c);
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;

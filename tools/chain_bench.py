@@ -1,0 +1,69 @@
+"""Isolated timing of the chained small forward layers (k_conv_chain) against the separate launches, BASELINE config 2 shapes.
+usage: python tools/chain_bench.py [B P]   (TUNING build: SSDN_CHAIN_ABLATE = 1 no MFMA loop, 2 no HBM stores, 4 no pool, 8 no weight stream)"""
+import os, sys, ctypes as C
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "selfsupervised-denoising_amd"), ROOT]
+import torch
+from ssdn.hip import lib as L
+from ssdn.hip.engine import DeviceNet, OpList, current_stream
+from ssdn.hip.graph import NetPlan
+
+B, P = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (32, 64)
+if os.environ.get("SSDN_LIB"):            # a -DSSDN_TUNING build of the library (ablation bits)
+    L.LIB_PATH = os.environ["SSDN_LIB"]
+lib = L.load()
+dev = torch.device("cuda:0")
+plan = NetPlan("m/", 3, 9, True, B, P, P, cus=lib.ssdn_device_cus())
+g = torch.Generator().manual_seed(5)
+flat = (torch.randn(plan.nparams, generator=g) * 0.08).to(dev)
+dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+dn.t["m/in32"].copy_(torch.rand(dn.t["m/in32"].shape, generator=g).to(dev))
+dn.pack.run(current_stream())
+recs = [dn._mat(op) for op in plan.fwd]
+OpList(recs).run(current_stream())
+best, at = 0, 0
+for i in range(len(recs)):
+    run = []
+    while i + len(run) < len(recs) and plan.fwd[i + len(run)].type == "conv" and len(run) < 8:
+        run.append(recs[i + len(run)])
+    if len(run) > 1:
+        arr = (C.c_void_p * len(run))(*[C.addressof(r[1]) for r in run])
+        n = lib.ssdn_conv_chain_len(arr, len(run))
+        if n > best:
+            best, at = n, i
+print("chain of %d layers at op %d: %s" % (best, at, [plan.fwd[at + k].a["layer"] for k in range(best)]))
+ol = OpList(recs[at:at + best])
+for on in (0, 1, 0, 1):
+    lib.ssdn_conv_set_chain(on)
+    for _ in range(20):
+        ol.run(current_stream())
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(200):
+        ol.run(current_stream())
+    e1.record()
+    torch.cuda.synchronize()
+    print("chain %d: %.2f us per pass" % (on, e0.elapsed_time(e1) * 1e3 / 200))
+
+if os.environ.get("SSDN_LIB"):
+    lib.ssdn_debug_set_trace.argtypes = [C.c_void_p]
+    N = 4 * B
+    tr = torch.zeros(N * 64, dtype=torch.int64, device=dev)
+    lib.ssdn_conv_set_chain(1)
+    lib.ssdn_debug_set_trace(tr.data_ptr())
+    ol.run(current_stream())
+    torch.cuda.synchronize()
+    lib.ssdn_debug_set_trace(None)
+    t = tr.cpu().view(N, 64)
+    nst = int((t[0] != 0).sum())
+    d = (t[:, 1:nst] - t[:, :nst - 1]).double()
+    names = ["start: zero, load, barriers"]
+    for i in range(best):
+        nch = plan.fwd[at + i].a["Ktot"] // 48
+        names += sum([["L%d chunk %d prologue" % (i, k), "L%d chunk %d 27 K-steps" % (i, k)] for k in range(nch)], [])
+        names += ["L%d epilogue" % i, "L%d barrier" % i, "L%d store" % i, "L%d pool" % i]
+    print("stamps per workgroup: %d; s_memtime ticks (mean over workgroups, min, max):" % nst)
+    for i in range(nst - 1):
+        print("  %-28s %8.1f %6d %6d" % (names[i] if i < len(names) else "?", float(d[:, i].mean()), int(d[:, i].min()), int(d[:, i].max())))
+    print("  total %.1f ticks" % float((t[:, nst - 1] - t[:, 0]).double().mean()))
