@@ -38,6 +38,8 @@ class OpList:
             self.arr[i].type = L.OP[ty]
             choices = self.LANE.get(ty, (0,)) if lanes else (0,)
             self.arr[i].lane = choices[count.get(ty, 0) % len(choices)]
+            if lanes and len(r) > 2:                      # (type, args, lane): the planner chose the lane of this record itself
+                self.arr[i].lane = r[2]
             count[ty] = count.get(ty, 0) + 1
             self.arr[i].args = C.cast(C.pointer(a), C.c_void_p)
         self.n = len(recs)
@@ -129,9 +131,12 @@ class DeviceNet:
                 last[k] = max(last.get(k, -1), flush_at[k] if grouped(op) else i)
         out, names, pending = [], [], {k: [] for k in range(len(buckets))}
         pending_small = {k: [] for k in range(len(buckets))}
+        pending_main = {k: [] for k in range(len(buckets))}
         for i, (op, rec) in enumerate(zip(plan.bwd, recs)):
             if op.type == "wreduce":
                 pending[bucket_of[op.a["layer"]]].append((rec, op.a["layer"]))
+            elif op.type == "wgrad" and op.a["layer"] in MAIN_LANE_WGRADS:
+                pending_main[bucket_of[op.a["layer"]]].append((rec[0], rec[1], 0))
             elif grouped(op):
                 pending_small[bucket_of[op.a["layer"]]].append(rec)
             else:
@@ -144,6 +149,9 @@ class DeviceNet:
                     pending_small[k] = []
             for k in sorted(last):
                 if last[k] == i:
+                    out += pending_main[k]
+                    names += [None] * len(pending_main[k])
+                    pending_main[k] = []
                     for rec_k, name_k in pending[k]:
                         out.append(rec_k)
                         names.append(name_k)
@@ -254,6 +262,12 @@ class DeviceNet:
                                            _ptr(self.t[P + "gmax"]), _ptr(self.t[P + "scale"]))
         raise ValueError("unknown op type " + op.type)
 
+
+# Weight-gradient GEMMs that run on the MAIN lane, after the last data-gradient launch of their gradient bucket, instead of the
+# weight-gradient lane: the backward pass ends with lane 1 still working through its queue (120 us) while lane 0 has nothing left.
+# Measured on the bench workload (tools/ab_lanes.py, same process): the first layer's gradient there -25 us per step; with
+# encode_block_2.0 or encode_block_1.2 as well -16 us.  Same kernels, same slabs: bit-identical.
+MAIN_LANE_WGRADS = ("encode_block_1.0",)
 
 STYLE = {"gauss": 0, "poisson": 1}
 MODE = {"known": 0, "const": 1, "var": 2}

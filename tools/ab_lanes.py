@@ -1,4 +1,4 @@
-"""Same-process A/B of lane assignments of the backward list (engine.SMALL_WGRAD_LANE / REDUCE_LANE) on the bench workload."""
+"""Same-process A/B of lane assignments of the backward list (engine.MAIN_LANE_WGRADS) on the bench workload."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "selfsupervised-denoising_amd"), ROOT]
@@ -10,16 +10,14 @@ from ssdn.datasets import DevicePatchStream, NoisyDataset
 from ssdn.params import NoiseAlgorithm
 
 dev = torch.device("cuda", 0)
-VARIANTS = [(1, 1), (3, 2), (3, 1), (1, 2)]
-if len(sys.argv) > 1:
-    VARIANTS = [tuple(int(x) for x in v.split(",")) for v in sys.argv[1:]]
+VARIANTS = [(), ("encode_block_1.0",), ("encode_block_1.0", "encode_block_2.0"), ("encode_block_1.2",), ("encode_block_1.0", "encode_block_1.2")]
 nd = NoisyDataset(None, "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
 g = torch.Generator().manual_seed(1)
 u8 = [torch.randint(0, 256, (32, 3, 64, 64), generator=g, dtype=torch.uint8).pin_memory() for _ in range(4)]
 idx = torch.arange(32)
 runs = {}
 for v in VARIANTS:
-    E.SMALL_WGRAD_LANE, E.REDUCE_LANE = v
+    E.MAIN_LANE_WGRADS = v
     torch.manual_seed(0)
     d = Denoiser(B.make_cfg(), device=str(dev))
     d.train()
@@ -47,6 +45,6 @@ for rnd in range(4):
         torch.cuda.synchronize()
         res[v].append(1e3 * (time.perf_counter() - t0) / N)
 for v in VARIANTS:
-    print("small-wgrad lane %d, reduce lane %d: ms/step %s  median %.4f" % (v[0], v[1], [round(x, 4) for x in res[v]], sorted(res[v])[len(res[v]) // 2]))
+    print("main-lane wgrads %s: ms/step %s  median %.4f" % (v, [round(x, 4) for x in res[v]], sorted(res[v])[len(res[v]) // 2]))
 w = [runs[v][1].flat.clone() for v in VARIANTS]
 print("weights identical across variants:", all(torch.equal(w[0], x) for x in w[1:]))
