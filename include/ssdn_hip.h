@@ -452,14 +452,17 @@ int ssdn_conv_fuses_upsum(const ssdn_conv_args* a);
 /* 1 if SSDN_OP_CONV with these arguments applies the fused SSDN_OP_UNROT_BWD (ssdn_conv_args.unrot), 0 if it cannot. */
 int ssdn_conv_fuses_unrot(const ssdn_conv_args* a);
 
-/* ssdn_run_ops executes a run of consecutive SSDN_OP_CONV ops on one lane as ONE launch (k_conv_chain, csrc/conv_chain.hip: one
- * workgroup per image walks all layers with the activations resident in LDS) when the run is a "chain": forward role (bf16 = 0),
- * 3x3 layers with identical taps and N, power-of-two images of at most 64 pixels, kc = 48 with c0, c1 multiples of 48,
- * bias + LeakyReLU, 16-bit output, no mask / add / upsum / unrot; a source is either the dst / pool view of an earlier layer of
- * the run (same p, cs, co, matching shape) or a tensor no layer of the run writes; every dst and pool is still written to HBM.
- * The result is bit-identical to one launch per op.  ssdn_conv_chain_len returns how many ops of the prefix of items[0..n) run as
- * one launch (0 = none, else >= 2; at most 8); ssdn_conv_set_chain(0) switches the merging off (test aid), (1) on (default). */
-int ssdn_conv_chain_len(const ssdn_conv_args* const* items, int n);
+/* ssdn_run_ops executes a run of consecutive ops on one lane as ONE launch (k_conv_chain, csrc/conv_chain.hip: one workgroup per
+ * image walks all layers with every tensor of the run resident in LDS) when the run is a "chain":
+ *   - SSDN_OP_CONV ops, all forward (bf16 = 0: bias + LeakyReLU, 16-bit output, optional fused max-pool) or all data gradients
+ *     (bf16 = 1: one source, optional mask / add / fused upsum), plus -- between data gradients -- SSDN_OP_POOL_BWD ops;
+ *   - 3x3 layers with identical taps and N, power-of-two images of at most 64 pixels (pooled size for SSDN_OP_POOL_BWD), kc = 48
+ *     with c0, c1 multiples of 48, no dst32 / unrot;
+ *   - a tensor read by an op is either written by an earlier op of the run (same p and cs, a channel window of what was written, same
+ *     shape) or written by no op of the run; every output is still written to HBM.
+ * The result is bit-identical to one launch per op.  ssdn_chain_len returns how many ops of the prefix of ops[0..n) run as one launch
+ * (0 = none, else >= 2; at most 12); ssdn_conv_set_chain(0) switches the merging off (test aid), (1) on (default). */
+int ssdn_chain_len(const ssdn_op* ops, int n);
 int ssdn_conv_set_chain(int on);
 
 /* ssdn_run_ops executes a run of consecutive SSDN_OP_WGRAD ops on one lane as ONE launch (k_wgrad_multi) when every op of the

@@ -198,14 +198,10 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
         hipStream_t s = lane_s[lane];
         switch (ops[i].type) {
             case SSDN_OP_PACK_INPUT: rc = launch_pack_input((const ssdn_pack_input_args*)p, s); break;
-            case SSDN_OP_CONV: {    // a run of consecutive small forward layers on the same lane is one launch (conv_chain.hip)
-                const ssdn_conv_args* items[CONV_CHAIN_MAX];
-                int m = 0;
-                while (m < CONV_CHAIN_MAX && i + m < n && ops[i + m].type == SSDN_OP_CONV && ops[i + m].args &&
-                       (one_lane ? 0 : ops[i + m].lane) == lane)
-                    items[m] = (const ssdn_conv_args*)ops[i + m].args, ++m;
-                m = m > 1 ? conv_chain_len(items, m) : 0;
-                if (m > 1) { rc = launch_conv_chain(items, m, s); i += m - 1; }
+            case SSDN_OP_CONV: {    // a run of consecutive small-image ops on the same lane is one launch (conv_chain.hip)
+                const int m = chain_len(ops + i, n - i, one_lane);
+                if (m < 0) return -1;
+                if (m > 1) { rc = launch_chain(ops + i, m, one_lane, s); i += m - 1; }
                 else rc = launch_conv((const ssdn_conv_args*)p, s);
                 break;
             }

@@ -118,10 +118,10 @@ int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s);
 int launch_noise(const ssdn_noise_args* a, hipStream_t s);
 int conv_lds_bytes(const ssdn_conv_args* a);
 int conv_validate(const ssdn_conv_args* a);                     // conv_mfma.hip: argument checks shared by every conv launcher
-// conv_chain.hip: a run of consecutive small 3x3 forward layers (images of <= 64 pixels) as ONE launch, activations resident in LDS
-#define CONV_CHAIN_MAX 8
-int conv_chain_len(const ssdn_conv_args* const* items, int n);   // layers of the prefix that runs as one launch (0 or >= 2)
-int launch_conv_chain(const ssdn_conv_args* const* items, int n, hipStream_t s);
+// conv_chain.hip: a run of consecutive main-lane ops on images of <= 64 pixels (3x3 forward layers; data gradients + SSDN_OP_POOL_BWD)
+// as ONE launch, one workgroup per image, tensors resident in LDS
+int chain_len(const ssdn_op* ops, int n, bool any_lane);         // ops of the prefix of ops[0..n) that run as one launch (0 or >= 2; < 0: error)
+int launch_chain(const ssdn_op* ops, int n, bool any_lane, hipStream_t s);
 // conv_dma.hip: persistent LDS-DMA convolution for the 3x3 layers that carry the flops
 bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size);
 int conv_dma_lds_bytes(int mt);

@@ -129,6 +129,27 @@ class DeviceNet:
             if op.type in ("wgrad", "wreduce"):
                 k = bucket_of[op.a["layer"]]
                 last[k] = max(last.get(k, -1), flush_at[k] if grouped(op) else i)
+        # The main-lane ops on images of <= 64 pixels (data gradients, max-pool backward) run as ONE launch when they are consecutive
+        # in the list (k_conv_chain, csrc/conv_chain.hip: the library's rule): side-lane records that would fall between them are
+        # emitted behind the last of them (a side-lane op may always be delayed).
+        def chainable(op):
+            if op.type == "conv":
+                return op.a["role"] == "dgrad" and len(op.a["taps"]) == 9 and op.a["H"] * op.a["W"] <= 64
+            return op.type == "pool_bwd" and (op.a["H"] // 2) * (op.a["W"] // 2) <= 64
+        windows, cur = [], None
+        for i, op in enumerate(plan.bwd):
+            if chainable(op):
+                cur = [i, i] if cur is None else [cur[0], i]
+            elif op.type not in ("wgrad", "wreduce") and cur is not None:
+                windows.append(cur)
+                cur = None
+        if cur is not None:
+            windows.append(cur)
+        for first, end in windows:
+            for d in (flush_at, last):
+                for k in d:
+                    if first <= d[k] < end:
+                        d[k] = end
         out, names, pending = [], [], {k: [] for k in range(len(buckets))}
         pending_small = {k: [] for k in range(len(buckets))}
         pending_main = {k: [] for k in range(len(buckets))}

@@ -131,7 +131,7 @@ ABI_VERSION = 7      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirro
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
-           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_conv_chain_len",
+           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_chain_len",
            "ssdn_conv_set_chain"]
 PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6)
 
@@ -174,8 +174,8 @@ def load() -> C.CDLL:
     lib.ssdn_conv_set_mode.restype = C.c_int
     lib.ssdn_conv_set_chain.argtypes = [C.c_int]
     lib.ssdn_conv_set_chain.restype = C.c_int
-    lib.ssdn_conv_chain_len.argtypes = [C.POINTER(C.c_void_p), C.c_int]
-    lib.ssdn_conv_chain_len.restype = C.c_int
+    lib.ssdn_chain_len.argtypes = [C.c_void_p, C.c_int]
+    lib.ssdn_chain_len.restype = C.c_int
     lib.ssdn_conv_fuses_unrot.argtypes = [C.c_void_p]
     lib.ssdn_conv_fuses_unrot.restype = C.c_int
     lib.ssdn_conv_fuses_upsum.argtypes = [C.c_void_p]

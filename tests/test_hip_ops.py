@@ -445,6 +445,18 @@ def test_merged_weight_gradient_launch_is_bit_identical():
     assert torch.equal(one_by_one[:n], merged[:n])
 
 
+def _longest_chain(lib, ol):
+    """longest run of ops the library executes as one k_conv_chain launch, over all start positions of the list"""
+    import ctypes as C
+    from ssdn.hip import lib as L
+    best = 0
+    for i in range(ol.n):
+        n = lib.ssdn_chain_len(C.byref(ol.arr, i * C.sizeof(L.OpRec)), ol.n - i)
+        assert n >= 0, lib.ssdn_last_error().decode()
+        best = max(best, n)
+    return best
+
+
 @pytest.fixture
 def conv_chain_reset():
     yield
@@ -472,16 +484,7 @@ def test_conv_chain_is_bit_identical(cin, cout, bs, B, P, min_chain, conv_chain_
     dn.t["m/in32"].copy_(torch.rand(dn.t["m/in32"].shape, generator=g).to(dev))
     dn.pack.run(current_stream())
     recs = [dn._mat(op) for op in plan.fwd]
-    # the longest chain the library finds in the forward list
-    best = 0
-    for i, op in enumerate(plan.fwd):
-        run = []
-        while i + len(run) < len(plan.fwd) and plan.fwd[i + len(run)].type == "conv" and len(run) < 8:
-            run.append(recs[i + len(run)])
-        if len(run) > 1:
-            arr = (C.c_void_p * len(run))(*[C.addressof(r[1]) for r in run])
-            best = max(best, lib.ssdn_conv_chain_len(arr, len(run)))
-    assert best >= min_chain, "the fixture must exercise the chained launch (longest chain: %d layers)" % best
+    assert _longest_chain(lib, OpList(recs)) >= min_chain, "the fixture must exercise the chained launch"
 
     def run_fwd(chain):
         L.check(lib.ssdn_conv_set_chain(int(chain)))
@@ -497,4 +500,45 @@ def test_conv_chain_is_bit_identical(cin, cout, bs, B, P, min_chain, conv_chain_
     assert torch.isfinite(separate["m/out32"]).all()
     bad = [name for name in separate if not torch.equal(separate[name].view(torch.int16 if separate[name].dtype == torch.float16 else torch.int32),
                                                         chained[name].view(torch.int16 if chained[name].dtype == torch.float16 else torch.int32))]
+    assert not bad, "tensors that differ between the chained and the separate launches: %s" % bad
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P,min_chain", [(3, 9, True, 4, 64, 10), (3, 9, True, 8, 32, 3), (3, 3, False, 16, 64, 10), (1, 2, True, 32, 64, 10)])
+def test_backward_chain_is_bit_identical(cin, cout, bs, B, P, min_chain, conv_chain_reset):
+    """The data gradients of the small layers -- with their fused epilogues (LeakyReLU' mask, skip-gradient add, fused up-sampling
+    adjoint) and the max-pool backward ops between them -- execute as ONE launch (k_conv_chain<true>); every gradient tensor of the
+    backward pass and the flat parameter gradient must come out bit for bit as from the separate launches."""
+    from ssdn.hip import lib as L
+    from ssdn.hip.engine import DeviceNet, current_stream
+    from ssdn.hip.graph import NetPlan
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=lib.ssdn_device_cus())
+    g = torch.Generator(device="cpu").manual_seed(6)
+    flat = (torch.randn(plan.nparams, generator=g) * 0.08).to(dev)
+    dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+    dn.t["m/in32"].copy_(torch.rand(dn.t["m/in32"].shape, generator=g).to(dev))
+    dn.pack.run(current_stream())
+    dn.fwd.run(current_stream())
+    dn.t["m/g32"].copy_((torch.randn(dn.t["m/g32"].shape, generator=g) * 1e-3).to(dev))
+    dn.t["m/gmax"][0] = int(np.float32(dn.t["m/g32"].abs().max().item()).view(np.int32))
+    assert _longest_chain(lib, dn.bwd) >= min_chain, "the fixture must exercise the chained launch"
+
+    def run_bwd(chain):
+        L.check(lib.ssdn_conv_set_chain(int(chain)))
+        for name, t in dn.t.items():
+            if t.dtype == torch.bfloat16 and "/w" not in name:
+                t.fill_(float("nan"))
+        dn.grads.fill_(float("nan"))
+        dn.bwd.run(current_stream())
+        torch.cuda.synchronize()
+        out = {name: t.clone() for name, t in dn.t.items() if t.dtype == torch.bfloat16 and "/w" not in name}
+        out["grads"] = dn.grads[:plan.nparams].clone()
+        return out
+
+    separate = run_bwd(False)
+    chained = run_bwd(True)
+    assert torch.isfinite(separate["grads"]).all()
+    as_int = lambda t: t.view(torch.int16 if t.dtype == torch.bfloat16 else torch.int32)  # noqa: E731
+    bad = [name for name in separate if not torch.equal(as_int(separate[name]), as_int(chained[name]))]
     assert not bad, "tensors that differ between the chained and the separate launches: %s" % bad

@@ -19,20 +19,21 @@ flat = (torch.randn(plan.nparams, generator=g) * 0.08).to(dev)
 dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
 dn.t["m/in32"].copy_(torch.rand(dn.t["m/in32"].shape, generator=g).to(dev))
 dn.pack.run(current_stream())
-recs = [dn._mat(op) for op in plan.fwd]
-OpList(recs).run(current_stream())
+DIR = sys.argv[3] if len(sys.argv) > 3 else "fwd"
+if DIR == "fwd":
+    full, ops = dn.fwd, plan.fwd
+else:
+    dn.fwd.run(current_stream())
+    dn.t["m/g32"].copy_((torch.randn(dn.t["m/g32"].shape, generator=g) * 1e-3).to(dev))
+    full, ops = dn.bwd, None
+full.run(current_stream())
 best, at = 0, 0
-for i in range(len(recs)):
-    run = []
-    while i + len(run) < len(recs) and plan.fwd[i + len(run)].type == "conv" and len(run) < 8:
-        run.append(recs[i + len(run)])
-    if len(run) > 1:
-        arr = (C.c_void_p * len(run))(*[C.addressof(r[1]) for r in run])
-        n = lib.ssdn_conv_chain_len(arr, len(run))
-        if n > best:
-            best, at = n, i
-print("chain of %d layers at op %d: %s" % (best, at, [plan.fwd[at + k].a["layer"] for k in range(best)]))
-ol = OpList(recs[at:at + best])
+for i in range(full.n):
+    n = lib.ssdn_chain_len(C.byref(full.arr, i * C.sizeof(L.OpRec)), full.n - i)
+    if n > best:
+        best, at = n, i
+print("chain of %d ops at op %d" % (best, at))
+ol = OpList([(next(k for k, v in L.OP.items() if v == full.arr[at + j].type), full.args[at + j]) for j in range(best)])
 for on in (0, 1, 0, 1):
     lib.ssdn_conv_set_chain(on)
     for _ in range(20):
@@ -60,7 +61,7 @@ if os.environ.get("SSDN_LIB"):
     d = (t[:, 1:nst] - t[:, :nst - 1]).double()
     names = ["start: zero, load, barriers"]
     for i in range(best):
-        nch = plan.fwd[at + i].a["Ktot"] // 48
+        nch = ol.args[i].Ktot // 48 if hasattr(ol.args[i], "Ktot") else 0
         names += sum([["L%d chunk %d prologue" % (i, k), "L%d chunk %d 27 K-steps" % (i, k)] for k in range(nch)], [])
         names += ["L%d epilogue" % i, "L%d barrier" % i, "L%d store" % i, "L%d pool" % i]
     print("stamps per workgroup: %d; s_memtime ticks (mean over workgroups, min, max):" % nst)
