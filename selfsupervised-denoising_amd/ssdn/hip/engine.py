@@ -285,10 +285,11 @@ class DeviceNet:
 
 
 # Weight-gradient GEMMs that run on the MAIN lane, after the last data-gradient launch of their gradient bucket, instead of the
-# weight-gradient lane: the backward pass ends with lane 1 still working through its queue (120 us) while lane 0 has nothing left.
-# Measured on the bench workload (tools/ab_lanes.py, same process): the first layer's gradient there -25 us per step; with
-# encode_block_2.0 or encode_block_1.2 as well -16 us.  Same kernels, same slabs: bit-identical.
-MAIN_LANE_WGRADS = ("encode_block_1.0",)
+# weight-gradient lane: the backward pass ends with lane 1 still working through its queue (150 us) while lane 0 has nothing left.
+# Measured on the bench workload (tools/ab_lanes.py, same process, with the chained small layers): encode_block_1.0 alone 2.031 ms
+# per step (2.056 with none), with encode_block_1.2 1.985, with encode_block_2.0 instead 2.005, all three 2.034.  Same kernels,
+# same slabs: bit-identical.
+MAIN_LANE_WGRADS = ("encode_block_1.0", "encode_block_1.2")
 
 STYLE = {"gauss": 0, "poisson": 1}
 MODE = {"known": 0, "const": 1, "var": 2}

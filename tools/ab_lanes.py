@@ -10,7 +10,7 @@ from ssdn.datasets import DevicePatchStream, NoisyDataset
 from ssdn.params import NoiseAlgorithm
 
 dev = torch.device("cuda", 0)
-VARIANTS = [(), ("encode_block_1.0",), ("encode_block_1.0", "encode_block_2.0"), ("encode_block_1.2",), ("encode_block_1.0", "encode_block_1.2")]
+VARIANTS = [("encode_block_1.0",), ("encode_block_1.0", "encode_block_1.2"), ("encode_block_1.0", "encode_block_2.0"), ("encode_block_1.0", "encode_block_1.2", "encode_block_2.0"), ("encode_block_1.2",)]
 nd = NoisyDataset(None, "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
 g = torch.Generator().manual_seed(1)
 u8 = [torch.randint(0, 256, (32, 3, 64, 64), generator=g, dtype=torch.uint8).pin_memory() for _ in range(4)]
