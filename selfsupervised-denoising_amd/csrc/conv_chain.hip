@@ -26,6 +26,7 @@
 // the same MFMA instruction and k-slot assignment as k_conv's flat path, and the epilogue arithmetic is applied to the same rounded
 // values in the same order (tests/test_hip_ops.py::test_conv_chain_is_bit_identical, ::test_backward_chain_is_bit_identical).
 #include "common.h"
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 #include <vector>
@@ -59,8 +60,7 @@ struct ChLayer {
     unsigned npc_magic;            // magic reciprocal of M / 8 (16-byte pieces per pixel): exact e / npc for e * npc < 2^32
     ssdn_view dst;                 // channels [dst_c0, M) of the output go to HBM here (p == NULL: none)
     int dst_c0;
-    int has_add;                   // backward: + skip gradient (bf16 plane AD) ...
-    ChPlane AD;
+    ChAux AD;                      // backward: + skip gradient (bf16) ...
     ChAux MK;                      // ... x LeakyReLU'(saved activation);  POOL_BWD: the full-resolution activation
     int has_pool, pool_shifted;    // forward: fused Shift2d + MaxPool2d into PP / pool;  POOL_BWD: pool_shifted = shifted
     ChPlane PP;
@@ -69,7 +69,8 @@ struct ChLayer {
     ChPlane PU;
     ChAux UM;
     ssdn_view upsum;
-    int has_pd, pad_;              // POOL_BWD: dz is also kept as a plane
+    int has_pd;                    // POOL_BWD: dz is also kept as a plane
+    int zero_off[2], zero_bytes[2], pad_;   // LDS ranges to clear before the layer writes its output planes (halo planes that reuse the space of dead ones)
 };
 struct ChainArgs {
     int N, nloads, nlayers, lds_bytes;
@@ -104,7 +105,7 @@ static __device__ __forceinline__ f32x16 ch_mma(half8 a, half8 b, f32x16 c) {
 
 // one 32-row output tile of one layer on this wave: K loop + register epilogue into the output plane
 template <int NPT, bool BF, typename STAMP>
-static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChLayer& L, char* smem, int mt, int l31, int kh,
+static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChLayer& L, char* smem, int mt, int pg, int l31, int kh,
                                                   half8 (&wr)[27], const h16* next_lanep, int next_tapstride, STAMP stamp) {
     const ChPlane P0 = L.P0, P1 = L.P1, PD = L.PD;
     const int HWp = 1 << (PD.lw + PD.lh);
@@ -121,7 +122,7 @@ static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChLa
     int py[NPT], px[NPT];
 #pragma unroll
     for (int p = 0; p < NPT; ++p) {
-        int q = p * 32 + l31;
+        int q = (pg * NPT + p) * 32 + l31;
         if (q >= HWp) q = 0;                                   // image smaller than the column tile: surplus lanes compute pixel 0, store nothing
         py[p] = q >> PD.lw;
         px[p] = q & ((1 << PD.lw) - 1);
@@ -181,7 +182,7 @@ static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChLa
         if (m0 >= L.M) continue;
 #pragma unroll
         for (int p = 0; p < NPT; ++p) {
-            if (p * 32 + l31 >= HWp) continue;
+            if ((pg * NPT + p) * 32 + l31 >= HWp) continue;
             float v[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -217,10 +218,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
     };
     stamp();
     const int nlayers = c.nlayers;
-    // the wave's work items in order: (layer li, tile mt) for every conv layer, mt = wave, wave + 4, ..
-    auto lanep_of = [&](int li, int mt) { return c.ly[li].w + (long long)(mt * 32 + l31) * c.ly[li].Ktot + kh * 8; };
-    auto first_from = [&](int li) {                            // first conv layer >= li with a tile for this wave, or -1
-        while (li < nlayers && !(c.ly[li].kind == CH_CONV && wave * 32 < c.ly[li].Mpad)) ++li;
+    // the wave's work items in order: item it = wave, wave + 4, .. of every conv layer; item -> (32-row tile it / npg, group it % npg
+    // of up to four 32-pixel column tiles; npg = 2 for 256-pixel images, else 1)
+    auto npg_of = [&](int li) { return c.ly[li].PD.lw + c.ly[li].PD.lh > 7 ? 2 : 1; };
+    auto items_of = [&](int li) { return (c.ly[li].Mpad >> 5) * npg_of(li); };
+    auto lanep_of = [&](int li, int it) { return c.ly[li].w + (long long)((it / npg_of(li)) * 32 + l31) * c.ly[li].Ktot + kh * 8; };
+    auto first_from = [&](int li) {                            // first conv layer >= li with an item for this wave, or -1
+        while (li < nlayers && !(c.ly[li].kind == CH_CONV && wave < items_of(li))) ++li;
         return li < nlayers ? li : -1;
     };
     half8 wr[27];
@@ -247,14 +251,23 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
         const ChPlane PD = L.PD;
         const int lhw = PD.lw + PD.lh;
         const int npc = L.M >> 3;
+        if (L.zero_bytes[0]) {                                 // output planes of this layer lie where dead planes were: clear (halo = 0)
+#pragma unroll
+            for (int r = 0; r < 2; ++r)
+                for (int z = tid * 16; z < L.zero_bytes[r]; z += CH_THREADS * 16) *reinterpret_cast<half8*>(smem + L.zero_off[r] + z) = zero_h8();
+            lds_barrier();
+        }
         if (L.kind == CH_CONV) {
-            for (int mt = wave; mt * 32 < L.Mpad; mt += 4) {
-                int nli = li, nmt = mt + 4;
-                if (nmt * 32 >= L.Mpad) { nli = first_from(li + 1); nmt = wave; }
-                const h16* nlp = nli >= 0 ? lanep_of(nli, nmt) : lanep_of(li, mt) + (L.Ktot - 48);
+            const int npg = lhw > 7 ? 2 : 1, nitems = (L.Mpad >> 5) * npg;
+            for (int it = wave; it < nitems; it += 4) {
+                int nli = li, nit = it + 4;
+                if (nit >= nitems) { nli = first_from(li + 1); nit = wave; }
+                const h16* nlp = nli >= 0 ? lanep_of(nli, nit) : lanep_of(li, it) + (L.Ktot - 48);
                 const int nts = nli >= 0 ? c.ly[nli].Mpad * c.ly[nli].Ktot : L.Mpad * L.Ktot;
-                if (lhw > 5) chain_tile<2, BF>(c, L, smem, mt, l31, kh, wr, nlp, nts, stamp);
-                else chain_tile<1, BF>(c, L, smem, mt, l31, kh, wr, nlp, nts, stamp);
+                const int mt = it / npg, pg = it - mt * npg;
+                if (lhw > 7) chain_tile<4, BF>(c, L, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
+                else if (lhw > 5) chain_tile<2, BF>(c, L, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
+                else chain_tile<1, BF>(c, L, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
             }                                                  // (an idle wave keeps the chunk it holds for its next layer)
             stamp();
             lds_barrier();
@@ -263,7 +276,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
             {
                 const int total = npc << lhw;
                 h16* dst = (h16*)L.dst.p + L.dst.co;
-                const bool fix = BF && (L.has_add || L.MK.where);
+                const bool fix = BF && (L.AD.where || L.MK.where);
                 for (int e = tid; e < total; e += CH_THREADS) {
                     const int q = ch_div(e, L.npc_magic), cc = e - q * npc;
                     char* pp = ch_px(smem, PD, q >> PD.lw, q & ((1 << PD.lw) - 1)) + cc * 16;
@@ -271,12 +284,12 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                     if constexpr (BF) {
                         if (fix) {
                             u32x4_t ab = {0u, 0u, 0u, 0u}, mb = {0u, 0u, 0u, 0u};
-                            if (L.has_add) ab = *reinterpret_cast<const u32x4_t*>(ch_px(smem, L.AD, q >> PD.lw, q & ((1 << PD.lw) - 1)) + cc * 16);
+                            if (L.AD.where) ab = ch_aux(L.AD, smem, n, q, cc);
                             if (L.MK.where) mb = ch_aux(L.MK, smem, n, q, cc);
 #pragma unroll
                             for (int w = 0; w < 4; ++w) {
-                                float v0 = bf_lo(o[w]) + (L.has_add ? bf_lo(ab[w]) : 0.f);
-                                float v1 = bf_hi(o[w]) + (L.has_add ? bf_hi(ab[w]) : 0.f);
+                                float v0 = bf_lo(o[w]) + (L.AD.where ? bf_lo(ab[w]) : 0.f);
+                                float v1 = bf_hi(o[w]) + (L.AD.where ? bf_hi(ab[w]) : 0.f);
                                 if (L.MK.where) {
                                     v0 *= lrelu_grad(f16_lo(mb[w]));
                                     v1 *= lrelu_grad(f16_hi(mb[w]));
@@ -291,7 +304,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                 }
             }
             stamp();
-            bool wrote = BF && (L.has_add || L.MK.where);
+            bool wrote = BF && (L.AD.where || L.MK.where);
             if constexpr (BF) {
                 if (L.upsum_c > 0) {
                     // fused SSDN_OP_UPSUM_BWD: 2x2 sums (scan order, fp32) of the bf16 values of channels [0, upsum_c), x LeakyReLU'(UM)
@@ -435,6 +448,8 @@ struct PlaneRec {
     bool halo;              // read by a convolution
     int hidden_c;           // channels [0, hidden_c) never reach HBM in this form (raw sums of an up-summed half): no reader may see them
     int off;
+    int first, last;        // layers that create (-1: loaded at the start) / last read the plane
+    int bytes;
 };
 struct PlaneRef { int idx = -1; int coff = 0; };   // plane + channel offset of the window inside it
 struct AuxRef { int where = 0; PlaneRef pl; ssdn_view v{nullptr, 0, 0}; int H = 1, W = 1; };
@@ -442,20 +457,21 @@ struct LayerRec {
     int kind;
     const ssdn_conv_args* a;
     const ssdn_pool_args* pa;
-    PlaneRef p0, p1, pd, ad, pp, pu;
-    AuxRef mk, um;
+    PlaneRef p0, p1, pd, pp, pu;
+    AuxRef mk, um, ad;
 };
 struct ChainBuild {
     std::vector<PlaneRec> planes;
     std::vector<LayerRec> layers;
     int nloads = 0;
+    int cur = 0;            // layer being built (plane lifetimes)
     int padT = 0, padB = 0, padL = 0, padR = 0;
 };
 }  // namespace
 
 static int cb_add_plane(ChainBuild& b, const ssdn_view& v, int H, int W, int C, bool produced, int hidden_c = 0) {
     if ((int)b.planes.size() >= CH_MAX_PLANES) return -1;
-    b.planes.push_back(PlaneRec{v, H, W, C, produced, false, hidden_c, 0});
+    b.planes.push_back(PlaneRec{v, H, W, C, produced, false, hidden_c, 0, produced ? b.cur : -1, b.cur, 0});
     return (int)b.planes.size() - 1;
 }
 // the plane (+ channel offset) that holds channels [v.co, v.co + C) of tensor v at H x W: an existing one, a new load from HBM, or
@@ -466,7 +482,11 @@ static PlaneRef cb_source(ChainBuild& b, const ssdn_view& v, int H, int W, int C
         const PlaneRec& P = b.planes[i];
         if (P.v.p != v.p) continue;
         const int rel = v.co - P.v.co;
-        if (P.v.cs == v.cs && P.H == H && P.W == W && rel >= P.hidden_c && rel + C <= P.C && rel >= 0) { r.idx = i; r.coff = rel; return r; }
+        if (P.v.cs == v.cs && P.H == H && P.W == W && rel >= P.hidden_c && rel + C <= P.C && rel >= 0) {
+            r.idx = i; r.coff = rel;
+            b.planes[i].last = b.cur;
+            return r;
+        }
         if (P.produced) { r.idx = -2; return r; }
     }
     r.idx = -2;
@@ -504,7 +524,8 @@ static bool chain_conv_ok(const ssdn_conv_args* a, const ssdn_conv_args* first) 
     if (conv_validate(a)) return false;
     if (a->bf16 != first->bf16 || a->ntaps != 9 || a->dst32 || a->unrot.p) return false;
     if (a->kc != 48 || a->Ktot % 48 || a->c0 % 48 || a->c1 % 48 || a->Ktot <= 0) return false;
-    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || a->H * a->W > 64) return false;
+    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || a->H * a->W > 256 || a->H * a->W == 128) return false;
+    if (a->H * a->W > 64 && (a->Mpad > 64 || a->Ktot > 48 || a->upsum.p)) return false;   // 256 pixels: only the thin (48-channel) layers pay
     if ((a->M & 7) || a->Mpad > 32 * 8 || a->N != first->N) return false;
     if (a->up0 && (a->c0 == 0 || ((a->H | a->W) & 1))) return false;
     if ((a->src0.cs & 7) || (a->src0.co & 7) || (a->c1 && ((a->src1.cs & 7) || (a->src1.co & 7)))) return false;
@@ -525,21 +546,24 @@ static bool chain_conv_ok(const ssdn_conv_args* a, const ssdn_conv_args* first) 
 }
 static bool chain_pool_ok(const ssdn_pool_args* a, int N) {
     if ((a->C & 7) || (a->H & 1) || (a->W & 1) || a->N != N) return false;
-    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || (a->H / 2) * (a->W / 2) > 64) return false;
+    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || (a->H / 2) * (a->W / 2) > 256) return false;
     for (const ssdn_view* v : {&a->act, &a->dpool, &a->dz})
         if (!v->p || (v->cs & 7) || (v->co & 7)) return false;
     return true;
 }
 
 // try to run exactly items[0..n) as one launch; on success fills *out (LDS offsets assigned)
+// (tuning builds: SSDN_CHAIN_DEBUG=1 says which rule ended a candidate run)
+#define CH_FAIL(code) do { if (ssdn_tuning_env("SSDN_CHAIN_DEBUG")) fprintf(stderr, "chain_build(%d ops): rule %d at op %d\n", n, code, dbg_i); return false; } while (0)
 static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
-    if (n < 2 || n > CH_MAX_LAYERS || items[0].type != SSDN_OP_CONV) return false;
+    int dbg_i = -1;
+    if (n < 2 || n > CH_MAX_LAYERS || items[0].type != SSDN_OP_CONV) CH_FAIL(1);
     const ssdn_conv_args* f = (const ssdn_conv_args*)items[0].args;
     ChainBuild b;
     int mny = 0, mxy = 0, mnx = 0, mxx = 0;
     unsigned tdy = 0, tdx = 0;
     for (int t = 0; t < 9; ++t) {
-        if (f->dy[t] < -4 || f->dy[t] > 3 || f->dx[t] < -4 || f->dx[t] > 3) return false;
+        if (f->dy[t] < -4 || f->dy[t] > 3 || f->dx[t] < -4 || f->dx[t] > 3) CH_FAIL(7);
         tdy |= (unsigned)(f->dy[t] + 4) << (3 * t);
         tdx |= (unsigned)(f->dx[t] + 4) << (3 * t);
         mny = f->dy[t] < mny ? f->dy[t] : mny; mxy = f->dy[t] > mxy ? f->dy[t] : mxy;
@@ -548,55 +572,77 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
     b.padT = -mny; b.padB = mxy; b.padL = -mnx; b.padR = mxx;
     for (int i = 0; i < n; ++i) {
         LayerRec R{};
+        b.cur = i;
+        dbg_i = i;
         if (items[i].type == SSDN_OP_CONV) {
             const ssdn_conv_args* a = (const ssdn_conv_args*)items[i].args;
-            if (!chain_conv_ok(a, f)) return false;
+            if (!chain_conv_ok(a, f)) CH_FAIL(19);
             R.kind = CH_CONV; R.a = a;
             if (a->c0 > 0) {
                 R.p0 = cb_source(b, a->src0, a->up0 ? a->H / 2 : a->H, a->up0 ? a->W / 2 : a->W, a->c0);
-                if (R.p0.idx < 0) return false;
+                if (R.p0.idx < 0) CH_FAIL(23);
                 b.planes[R.p0.idx].halo = true;
             }
             if (a->c1 > 0) {
                 R.p1 = cb_source(b, a->src1, a->H, a->W, a->c1);
-                if (R.p1.idx < 0) return false;
+                if (R.p1.idx < 0) CH_FAIL(28);
                 b.planes[R.p1.idx].halo = true;
             }
             if (a->bf16) {
-                if (a->add.p) { R.ad = cb_source(b, a->add, a->H, a->W, a->M); if (R.ad.idx < 0) return false; }
-                if (a->mask.p && !cb_aux(b, a->mask, a->H, a->W, a->M, &R.mk)) return false;
-                if (a->upsum.p && !cb_aux(b, a->upsum_mask, a->H / 2, a->W / 2, a->upsum_c, &R.um)) return false;
+                if (a->add.p && !cb_aux(b, a->add, a->H, a->W, a->M, &R.ad)) CH_FAIL(32);
+                if (a->mask.p && !cb_aux(b, a->mask, a->H, a->W, a->M, &R.mk)) CH_FAIL(33);
+                if (a->upsum.p && !cb_aux(b, a->upsum_mask, a->H / 2, a->W / 2, a->upsum_c, &R.um)) CH_FAIL(34);
             }
             // an output tensor that is already mirrored by a plane (written twice, or written after it was loaded) is not a chain
-            if ((a->dst.p && cb_written(b, a->dst.p)) || (a->pool.p && cb_written(b, a->pool.p)) || (a->upsum.p && cb_written(b, a->upsum.p))) return false;
+            if ((a->dst.p && cb_written(b, a->dst.p)) || (a->pool.p && cb_written(b, a->pool.p)) || (a->upsum.p && cb_written(b, a->upsum.p))) CH_FAIL(37);
             ssdn_view dv = a->dst;
             if (!dv.p) { dv.p = (void*)a; dv.cs = 0; dv.co = 0; }           // (never read back: a private key)
             R.pd.idx = cb_add_plane(b, dv, a->H, a->W, a->M, true, a->upsum.p ? a->upsum_c : 0);
-            if (R.pd.idx < 0) return false;
-            if (a->pool.p) { R.pp.idx = cb_add_plane(b, a->pool, a->H / 2, a->W / 2, a->M, true); if (R.pp.idx < 0) return false; }
-            if (a->upsum.p) { R.pu.idx = cb_add_plane(b, a->upsum, a->H / 2, a->W / 2, a->upsum_c, true); if (R.pu.idx < 0) return false; }
+            if (R.pd.idx < 0) CH_FAIL(41);
+            if (a->pool.p) { R.pp.idx = cb_add_plane(b, a->pool, a->H / 2, a->W / 2, a->M, true); if (R.pp.idx < 0) CH_FAIL(42); }
+            if (a->upsum.p) { R.pu.idx = cb_add_plane(b, a->upsum, a->H / 2, a->W / 2, a->upsum_c, true); if (R.pu.idx < 0) CH_FAIL(43); }
         } else if (items[i].type == SSDN_OP_POOL_BWD) {
             const ssdn_pool_args* a = (const ssdn_pool_args*)items[i].args;
-            if (!f->bf16 || !chain_pool_ok(a, f->N)) return false;
+            if (!f->bf16 || !chain_pool_ok(a, f->N)) CH_FAIL(46);
             R.kind = CH_POOL_BWD; R.pa = a;
             R.p0 = cb_source(b, a->dpool, a->H / 2, a->W / 2, a->C);
-            if (R.p0.idx < 0) return false;
-            if (!cb_aux(b, a->act, a->H, a->W, a->C, &R.mk)) return false;
-            if (cb_written(b, a->dz.p)) return false;
-            if (a->H * a->W <= 64) { R.pd.idx = cb_add_plane(b, a->dz, a->H, a->W, a->C, true); if (R.pd.idx < 0) return false; }
-        } else return false;
+            if (R.p0.idx < 0) CH_FAIL(49);
+            if (!cb_aux(b, a->act, a->H, a->W, a->C, &R.mk)) CH_FAIL(50);
+            if (cb_written(b, a->dz.p)) CH_FAIL(51);
+            if (a->H * a->W <= 256) { R.pd.idx = cb_add_plane(b, a->dz, a->H, a->W, a->C, true); if (R.pd.idx < 0) CH_FAIL(52); }
+        } else CH_FAIL(53);
         b.layers.push_back(R);
     }
-    // ---- LDS layout ----
+    // ---- LDS layout: a plane may take the space of planes that were last read two or more layers before it is created (every wave
+    //      has passed a barrier since); first fit, lowest offset ----
     int lds = 0;
-    for (PlaneRec& P : b.planes) {
+    std::vector<std::vector<std::pair<int, int>>> zero((size_t)n);
+    for (int i = 0; i < (int)b.planes.size(); ++i) {
+        PlaneRec& P = b.planes[i];
         const int str = P.C * 2 + 16;
         const int rows = P.halo ? P.H + b.padT + b.padB : P.H, roww = P.halo ? P.W + b.padL + b.padR : P.W;
-        P.off = lds;
-        lds += rows * roww * str;
-        lds = (lds + 15) & ~15;
+        P.bytes = (rows * roww * str + 15) & ~15;
+        int off = 0;
+        bool moved = true, reused = false;
+        while (moved) {
+            moved = false;
+            for (int j = 0; j < i; ++j) {
+                const PlaneRec& Q = b.planes[j];
+                if (off >= Q.off + Q.bytes || off + P.bytes <= Q.off) continue;
+                if (P.first >= 0 && Q.last + 2 <= P.first) continue;          // dead long enough: may be overwritten
+                off = Q.off + Q.bytes;
+                moved = true;
+            }
+        }
+        for (int j = 0; j < i; ++j)
+            if (!(off >= b.planes[j].off + b.planes[j].bytes || off + P.bytes <= b.planes[j].off)) reused = true;
+        P.off = off;
+        lds = off + P.bytes > lds ? off + P.bytes : lds;
+        if (reused && P.halo) zero[P.first].push_back({off, P.bytes});   // stale bytes under a halo: the producing layer clears the plane first
     }
-    if (lds > 160 * 1024) return false;
+    if (lds > 160 * 1024) CH_FAIL(86);
+    for (int i = 0; i < n; ++i)
+        if (zero[i].size() > 2) CH_FAIL(87);
     auto desc = [&](PlaneRef r) {
         ChPlane D{};
         if (r.idx < 0) return D;
@@ -635,7 +681,7 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
             L.P1 = desc(R.p1.idx >= 0 ? R.p1 : R.p0);
             L.PD = desc(R.pd);
             L.dst = a->dst; L.dst_c0 = a->upsum.p ? a->upsum_c : 0;
-            L.has_add = R.ad.idx >= 0; L.AD = desc(R.ad);
+            L.AD = aux(R.ad);
             L.MK = aux(R.mk);
             L.has_pool = R.pp.idx >= 0; L.pool_shifted = a->pool_shifted; L.PP = desc(R.pp); L.pool = a->pool;
             L.upsum_c = a->upsum.p ? a->upsum_c : 0; L.PU = desc(R.pu); L.UM = aux(R.um); L.upsum = a->upsum;
@@ -649,12 +695,14 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
             L.MK = aux(R.mk);
             L.dst = a->dz; L.pool_shifted = a->shifted;
         }
+        for (size_t r = 0; r < zero[i].size(); ++r) { L.zero_off[r] = zero[i][r].first; L.zero_bytes[r] = zero[i][r].second; }
         const unsigned npc = (unsigned)L.M / 8;
         L.npc_magic = npc <= 1 ? 0u : (unsigned)((0x100000000ull + npc - 1) / npc);
     }
     return true;
 }
 
+#undef CH_FAIL
 // plans of the op-list runs seen so far (the op lists of an engine are static: a handful per process), keyed by the runs' argument bytes
 namespace {
 struct ChainHit { int len = 0; ChainArgs* dev = nullptr; size_t lds = 0; int N = 0; int bf = 0; };
@@ -671,7 +719,7 @@ static int chain_lookup(const ssdn_op* ops, int n, bool any_lane, ChainHit* hit)
     *hit = ChainHit{};
     if (!g_chain_on || n < 2 || ops[0].type != SSDN_OP_CONV || !ops[0].args) return 0;
     const ssdn_conv_args* f = (const ssdn_conv_args*)ops[0].args;
-    if (f->H * f->W > 64 || f->ntaps != 9 || f->kc != 48) return 0;            // (cheap reject before any bookkeeping)
+    if (f->H * f->W > 256 || f->ntaps != 9 || f->kc != 48) return 0;           // (cheap reject before any bookkeeping)
     int m = 0;
     while (m < n && m < CH_MAX_LAYERS && (ops[m].type == SSDN_OP_CONV || ops[m].type == SSDN_OP_POOL_BWD) && ops[m].args &&
            (any_lane || ops[m].lane == ops[0].lane)) ++m;
@@ -691,6 +739,8 @@ static int chain_lookup(const ssdn_op* ops, int n, bool any_lane, ChainHit* hit)
     ChainArgs host;
     for (int len = m; len >= 2; --len)
         if (chain_build(ops, len, &host)) { cc.hit.len = len; break; }
+    if (cc.hit.len && ssdn_tuning_env("SSDN_CHAIN_DEBUG"))
+        fprintf(stderr, "conv chain: %d of %d candidate ops, %s, N %d, LDS %d B, %d loads\n", cc.hit.len, m, host.bf ? "bwd" : "fwd", host.N, host.lds_bytes, host.nloads);
     if (cc.hit.len) {
         static const int env_ablate = [] { const char* e = ssdn_tuning_env("SSDN_CHAIN_ABLATE"); return e ? atoi(e) : 0; }();
         host.ablate = env_ablate;

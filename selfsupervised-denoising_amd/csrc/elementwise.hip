@@ -388,28 +388,47 @@ __global__ void k_wreduce_partial(float* slab, long long stride, int nslabs) {
     for (; s < s1; ++s) { float4 v = p[(long long)s * st4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
     p[(long long)s0 * st4] = acc;
 }
-// stage 2 (or the only stage when nslabs <= 32): one thread per slab element in SLAB order (k fastest), slabs
-// s = 0, step, 2*step, ... summed in order; writes the OIHW gradient.
+// stage 2 (or the only stage when nslabs <= 32): one thread per FOUR consecutive slab elements in SLAB order (k fastest; Kpad is a
+// multiple of 4, so they share their row), slabs s = 0, step, 2*step, ... summed in order -- eight 16-byte loads in flight per round
+// (one 4-byte load per slab in a dependent loop was a latency chain: 24 us per bucket alone, 70 us in situ); writes the OIHW gradient.
 static __device__ __forceinline__ void wreduce_final(const ssdn_wreduce_args& a, int step, long long idx) {
-    long long stride = (long long)a.ntaps * a.Mpad * a.Kpad;
+    const long long stride = (long long)a.ntaps * a.Mpad * a.Kpad, stride4 = stride >> 2;
     float inv = a.inv_scale ? *a.inv_scale : 1.f;
-    if (idx < stride) {
-        int k = idx % a.Kpad;
-        int m = (idx / a.Kpad) % a.Mpad;
-        int t = idx / ((long long)a.Kpad * a.Mpad);
-        int ci = a.tapblock ? t * a.Kpad + k : k;
-        if (k < (a.tapblock ? a.Kpad : a.cin) && ci < a.cin && m < a.M) {
-            const float* p = a.slab + idx;
-            float acc = 0.f;
-            for (int s = 0; s < a.nslabs; s += step) acc += p[(long long)s * stride];
-            long long o = a.tapblock ? ((long long)(a.m_off + m) * a.cin_full + a.c_off + ci)
-                                     : ((long long)(a.m_off + m) * a.cin_full + a.c_off + k) * a.ntaps + t;
-            a.gw[o] = acc * inv;
+    if (idx < stride4) {
+        const long long e0 = idx * 4;
+        int k = e0 % a.Kpad;
+        int m = (e0 / a.Kpad) % a.Mpad;
+        int t = e0 / ((long long)a.Kpad * a.Mpad);
+        const int klim = a.tapblock ? a.Kpad : a.cin;
+        if (k < klim && (a.tapblock ? t * a.Kpad + k : k) < a.cin && m < a.M) {
+            const float4* p = reinterpret_cast<const float4*>(a.slab + e0);
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            const long long st4 = stride4 * step;
+            const int cnt = (a.nslabs + step - 1) / step;
+            int s = 0;
+            for (; s + 8 <= cnt; s += 8) {
+                float4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = p[(long long)(s + u) * st4];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) { acc.x += v[u].x; acc.y += v[u].y; acc.z += v[u].z; acc.w += v[u].w; }
+            }
+            for (; s < cnt; ++s) { const float4 v = p[(long long)s * st4]; acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+            const float r[4] = {acc.x, acc.y, acc.z, acc.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int kj = k + j, ci = a.tapblock ? t * a.Kpad + kj : kj;
+                if (kj < klim && ci < a.cin) {
+                    long long o = a.tapblock ? ((long long)(a.m_off + m) * a.cin_full + a.c_off + ci)
+                                             : ((long long)(a.m_off + m) * a.cin_full + a.c_off + kj) * a.ntaps + t;
+                    a.gw[o] = r[j] * inv;
+                }
+            }
         }
-    } else if (idx < stride + a.M && a.gb) {
+    } else if (idx < stride4 + a.M && a.gb) {
         // bias gradient: 16 independent loads in flight per round (a dependent one-at-a-time loop over 256 slabs is
         // pure L2 latency: it alone cost 30-60 us per layer), summed in slab order
-        int m = idx - stride;
+        int m = idx - stride4;
         float acc = 0.f;
         int s = 0;
         for (; s + 16 <= a.nslabs; s += 16) {
@@ -492,7 +511,8 @@ int launch_wreduce_multi(const ssdn_wreduce_args* const* items, int n, hipStream
         }
         t1.step[i] = t2.step[i];
         t2.gx[i] = t1.gx[i];
-        b2 += ew_grid(stride + a->M);
+        if (a->Kpad & 3) return ssdn_set_error("wreduce: Kpad must be a multiple of 4");
+        b2 += ew_grid(stride / 4 + a->M);
     }
     t1.bstart[n] = b1;
     t2.bstart[n] = b2;
@@ -509,7 +529,8 @@ int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s) {
         hipLaunchKernelGGL(k_wreduce_partial, dim3(ew_grid(stride / 4), groups), dim3(EW_BLOCK), 0, s, (float*)a->slab, stride, a->nslabs);
         step = WR_GROUP;
     }
-    long long n = stride + a->M;
+    if (a->Kpad & 3) return ssdn_set_error("wreduce: Kpad must be a multiple of 4");
+    long long n = stride / 4 + a->M;
     hipLaunchKernelGGL(k_wreduce, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a, step);
     return 0;
 }

@@ -134,8 +134,10 @@ class DeviceNet:
         # emitted behind the last of them (a side-lane op may always be delayed).
         def chainable(op):
             if op.type == "conv":
-                return op.a["role"] == "dgrad" and len(op.a["taps"]) == 9 and op.a["H"] * op.a["W"] <= 64
-            return op.type == "pool_bwd" and (op.a["H"] // 2) * (op.a["W"] // 2) <= 64
+                px = op.a["H"] * op.a["W"]
+                thin = px == 256 and op.a["Mpad"] <= 64 and op.a["Ktot"] <= 48 and op.a.get("upsum") is None
+                return op.a["role"] == "dgrad" and len(op.a["taps"]) == 9 and (px <= 64 or thin)
+            return op.type == "pool_bwd" and (op.a["H"] // 2) * (op.a["W"] // 2) <= 256
         windows, cur = [], None
         for i, op in enumerate(plan.bwd):
             if chainable(op):
