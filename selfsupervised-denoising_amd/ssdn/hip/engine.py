@@ -165,13 +165,23 @@ class DeviceNet:
             else:
                 out.append(rec)
                 names.append(None)
-            for k, idx in flush_at.items():
-                if idx == i:
+            for k in sorted(set(flush_at) | set(last)):          # bucket by bucket: a bucket's merged launch, then its reductions
+                if flush_at.get(k) == i:
                     out += pending_small[k]
                     names += [None] * len(pending_small[k])
                     pending_small[k] = []
+                if not SPLIT_SMALL_RUNS:
+                    continue
+                if last.get(k) == i:
+                    out += pending_main[k]
+                    names += [None] * len(pending_main[k])
+                    pending_main[k] = []
+                    for rec_k, name_k in pending[k]:
+                        out.append(rec_k)
+                        names.append(name_k)
+                    pending[k] = []
             for k in sorted(last):
-                if last[k] == i:
+                if last[k] == i and not SPLIT_SMALL_RUNS:
                     out += pending_main[k]
                     names += [None] * len(pending_main[k])
                     pending_main[k] = []
@@ -292,6 +302,9 @@ class DeviceNet:
 # per step (2.056 with none), with encode_block_1.2 1.985, with encode_block_2.0 instead 2.005, all three 2.034.  Same kernels,
 # same slabs: bit-identical.
 MAIN_LANE_WGRADS = ("encode_block_1.0", "encode_block_1.2")
+# True: when the merged small-layer launches of two gradient buckets end up next to each other in the list, the first bucket's
+# reductions go between them (two k_wgrad_multi launches); False: one launch for both, then both buckets' reductions.
+SPLIT_SMALL_RUNS = True
 
 STYLE = {"gauss": 0, "poisson": 1}
 MODE = {"known": 0, "const": 1, "var": 2}
