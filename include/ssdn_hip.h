@@ -132,8 +132,9 @@ typedef struct ssdn_conv_args {
                        pre-swizzled, [tap][chunk][Mpad][kc] with kc = 48 (chunks of 48 input channels, then one optional 16-channel
                        chunk); the 16-byte piece p of row m is stored at piece p ^ ((m >> 3) & 1) -- exactly the LDS image, so a
                        (tap, chunk) slice is one linear, fully coalesced DMA (SSDN_OP_WPACK writes it: wfc / wdc) */
-    int32_t kreal; /* real (un-padded) input channels among the Ktot slots: only used for the profiler's algorithmic flop count
-                      (0: = Ktot) */
+    int32_t kreal; /* real (un-padded) input channels among the Ktot slots (0: = Ktot): the algorithmic flop count of the profiler, and a
+                      CONTRACT for the forward role -- the input channels >= kreal are zero (SSDN_OP_PACK_INPUT pads with zeros), so a
+                      launch may skip them (k_conv_thin, csrc/conv_thin.hip, serves Ktot = 16 with kreal <= 3) */
     /* Fused Shift2d((1,0)) + nn.MaxPool2d(2) of the conv's activated 16-bit output (SSDN_OP_POOL_FWD semantics; the reference:
      * noise_network.py:64-67): pool.p != NULL makes the epilogue ALSO write pooled[N,H/2,W/2,M] -- the max is taken over the
      * rounded fp16 values the epilogue stores, so the result is bit-identical to SSDN_OP_POOL_FWD applied to dst.  Only the

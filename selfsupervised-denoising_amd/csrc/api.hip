@@ -197,7 +197,14 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
         used[lane] = true;
         hipStream_t s = lane_s[lane];
         switch (ops[i].type) {
-            case SSDN_OP_PACK_INPUT: rc = launch_pack_input((const ssdn_pack_input_args*)p, s); break;
+            case SSDN_OP_PACK_INPUT: {   // ... directly followed by the thin first layer that reads it: one launch (conv_thin.hip)
+                const bool next_conv = i + 1 < n && ops[i + 1].type == SSDN_OP_CONV && ops[i + 1].args && (one_lane ? 0 : ops[i + 1].lane) == lane;
+                if (next_conv && chain_merging_on() && conv_pack_fusable((const ssdn_pack_input_args*)p, (const ssdn_conv_args*)ops[i + 1].args)) {
+                    rc = launch_conv_thin((const ssdn_conv_args*)ops[i + 1].args, (const ssdn_pack_input_args*)p, s);
+                    ++i;
+                } else rc = launch_pack_input((const ssdn_pack_input_args*)p, s);
+                break;
+            }
             case SSDN_OP_CONV: {    // a run of consecutive small-image ops on the same lane is one launch (conv_chain.hip)
                 const int m = chain_len(ops + i, n - i, one_lane);
                 if (m < 0) return -1;

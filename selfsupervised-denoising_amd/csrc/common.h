@@ -122,6 +122,7 @@ int conv_validate(const ssdn_conv_args* a);                     // conv_mfma.hip
 // as ONE launch, one workgroup per image, tensors resident in LDS
 int chain_len(const ssdn_op* ops, int n, bool any_lane);         // ops of the prefix of ops[0..n) that run as one launch (0 or >= 2; < 0: error)
 int launch_chain(const ssdn_op* ops, int n, bool any_lane, hipStream_t s);
+bool chain_merging_on();                                         // ssdn_conv_set_chain: run merging (chains, folded input pack) enabled
 // conv_dma.hip: persistent LDS-DMA convolution for the 3x3 layers that carry the flops
 bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size);
 int conv_dma_lds_bytes(int mt);
@@ -129,6 +130,11 @@ bool conv_fuses_unrot(const ssdn_conv_args* a);                // conv_mfma.hip:
 bool conv_fuses_upsum(const ssdn_conv_args* a);                // conv_mfma.hip: k_cdma or the flat path applies the fused UPSUM_BWD
 bool conv_fuses_pool(const ssdn_conv_args* a);                  // conv_mfma.hip: the launch takes the flat path (fused max-pool)
 int launch_conv_dma(const ssdn_conv_args* a, hipStream_t s);
+// conv_thin.hip: forward 3x3 layer with 1..3 real input channels (encode_block_1.0) as an im2col-shaped GEMM
+bool conv_thin_eligible(const ssdn_conv_args* a);
+bool conv_thin_fuses_pack(const ssdn_pack_input_args* pk, const ssdn_conv_args* a);   // (the conv must still pass launch_conv's own routing)
+int launch_conv_thin(const ssdn_conv_args* a, const ssdn_pack_input_args* pk, hipStream_t s);
+bool conv_pack_fusable(const ssdn_pack_input_args* pk, const ssdn_conv_args* a);      // conv_mfma.hip: launch_conv would route `a` to k_conv_thin
 // gemm_dma.hip: 1x1 layers with 96 / 384 output channels as a one-pass LDS-DMA GEMM
 bool gemm_dma_eligible(const ssdn_conv_args* a);
 int gemm_dma_lds_bytes(const ssdn_conv_args* a);

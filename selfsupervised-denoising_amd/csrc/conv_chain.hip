@@ -432,6 +432,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 static bool g_chain_on = true;
 extern "C" int ssdn_conv_set_chain(int on) { g_chain_on = on != 0; return 0; }
+bool chain_merging_on() { return g_chain_on; }
 
 static int ilog2_exact(int v) {
     if (v <= 0 || (v & (v - 1))) return -1;

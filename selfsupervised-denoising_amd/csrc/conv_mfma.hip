@@ -785,6 +785,10 @@ extern "C" int ssdn_conv_set_mode(int mode) {
 // (a launch that must write the fused max-pool output takes k_conv's flat path)
 static bool conv_use_dma(const ssdn_conv_args* a) { return g_conv_mode > 0 && !a->pool.p && conv_dma_eligible(a, g_conv_mode == 2); }
 static bool conv_use_gemm(const ssdn_conv_args* a) { return g_conv_mode > 0 && gemm_dma_eligible(a); }
+static bool conv_use_thin(const ssdn_conv_args* a) { return g_conv_mode > 0 && conv_thin_eligible(a); }
+bool conv_pack_fusable(const ssdn_pack_input_args* pk, const ssdn_conv_args* a) {
+    return !conv_validate(a) && !conv_use_gemm(a) && conv_use_thin(a) && conv_thin_fuses_pack(pk, a);
+}
 
 int conv_validate(const ssdn_conv_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("conv: ntaps out of range");
@@ -814,6 +818,7 @@ static size_t conv_lds(const ssdn_conv_args* a, const ConvGeom& g, int mt) {
 int conv_lds_bytes(const ssdn_conv_args* a) {
     if (conv_validate(a)) return -1;
     if (conv_use_gemm(a)) return gemm_dma_lds_bytes(a);
+    if (conv_use_thin(a)) return 32 * 1024;                     // (halo of four channel slots + four wave-private transpose tiles: < 32 KB)
     if (conv_use_dma(a)) return conv_dma_lds_bytes(a->Mpad >= 96 ? 3 : a->Mpad / 32);
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     int mt = a->Mpad / 32;
@@ -916,6 +921,7 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     if (a->upsum.p && !conv_fuses_upsum(a)) return ssdn_set_error("conv: fused upsum requested for a launch that cannot fuse it (ssdn_conv_fuses_upsum)");
     if (a->pool.p && !conv_fuses_pool(a)) return ssdn_set_error("conv: fused max-pool requested for a launch that cannot fuse it (ssdn_conv_fuses_pool)");
     if (conv_use_gemm(a)) return launch_gemm_dma(a, s);
+    if (conv_use_thin(a)) return launch_conv_thin(a, nullptr, s);
     if (conv_use_dma(a)) return launch_conv_dma(a, s);
     ConvGeom g = conv_geom(a->ltw, a->lth, a->ltn, a->ntaps, a->dy, a->dx, a->N, a->H, a->W, a->kc);
     ConvAux x;

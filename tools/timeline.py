@@ -8,8 +8,8 @@ ks = []
 for r in rows:
     ks.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"], r.get("Queue_Id", "0"), r.get("Stream_Id", "0")))
 ks.sort()
-# steps are delimited by k_pack_input launches
-starts = [i for i, k in enumerate(ks) if "k_pack_input" in k[2]]
+# steps are delimited by the input pack (k_pack_input, or the first layer's launch that contains it: k_conv_thin<.., true>)
+starts = [i for i, k in enumerate(ks) if "k_pack_input" in k[2] or ("k_conv_thin" in k[2] and "true" in k[2])]
 si = int(sys.argv[2]) if len(sys.argv) > 2 else len(starts) // 2
 a, b = starts[si], starts[si + 1]
 step = ks[a:b]
