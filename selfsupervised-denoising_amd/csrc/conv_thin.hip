@@ -53,39 +53,66 @@ __global__ __launch_bounds__(CT_THREADS) void k_conv_thin(ssdn_conv_args a, int 
         }
     }
     // ---- the halo of the block: the first four channel slots of every pixel, zero outside the image; then one 8-byte zero slot ----
+    // (all loads of a thread's up to six halo entries are issued before the first is used: a guarded load per channel and pixel was a
+    //  chain of fifteen exposed L2 round trips)
     const h16* src = (const h16*)a.src0.p + a.src0.co;
-    for (int e = tid; e < HH * HW + 1; e += CT_THREADS) {
+    constexpr int NIT = 6;                                     // (16 + 4) x (64 + 4) + 1 entries at most
+    float f32v[NIT][3];
+    u32x2_t raw[NIT];
+    bool ok[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * CT_THREADS;
         const int hy = e / HW, hx = e - hy * HW;
         const int y = y0 - padT + hy, x = x0 - padL + hx;
-        u32x2_t v = {0u, 0u};
-        if (e < HH * HW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W) {
-            if constexpr (PACK) {
-                const int r = n / pk.B, b = n - r * pk.B, H = a.H, W = a.W;
-                int sy, sx;                                    // source coordinates in the un-rotated image (as k_pack_input)
-                switch (r) {
-                    case 0: sy = y; sx = x; break;
-                    case 1: sy = x; sx = W - 1 - y; break;
-                    case 2: sy = H - 1 - y; sx = W - 1 - x; break;
-                    default: sy = H - 1 - x; sx = y; break;
-                }
-                h16 c4[4] = {(h16)0.f, (h16)0.f, (h16)0.f, (h16)0.f};
-#pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    if (c < pk.C) c4[c] = (h16)pk.src[(((long long)b * pk.C + c) * H + sy) * W + sx];
-                v[0] = (unsigned)__builtin_bit_cast(unsigned short, c4[0]) | ((unsigned)__builtin_bit_cast(unsigned short, c4[1]) << 16);
-                v[1] = (unsigned)__builtin_bit_cast(unsigned short, c4[2]) | ((unsigned)__builtin_bit_cast(unsigned short, c4[3]) << 16);
-                if ((unsigned)(y - y0) < 16u && (unsigned)(x - x0) < 64u) {      // this block's own pixels: the packed row
-                    h16* d = (h16*)pk.dst.p + ((long long)(n * H + y) * W + x) * pk.dst.cs + pk.dst.co;
-                    const u32x4_t first = {v[0], v[1], 0u, 0u}, zero = {0u, 0u, 0u, 0u};
-                    for (int c0 = 0; c0 < pk.cpad; c0 += 8) *reinterpret_cast<u32x4_t*>(d + c0) = c0 == 0 ? first : zero;
-                }
-            } else {
-                v = *reinterpret_cast<const u32x2_t*>(src + ((long long)(n * a.H + y) * a.W + x) * a.src0.cs);
+        ok[it] = e < HH * HW && (unsigned)y < (unsigned)a.H && (unsigned)x < (unsigned)a.W;
+        const int yc = ok[it] ? y : 0, xc = ok[it] ? x : 0;
+        if constexpr (PACK) {
+            const int r = n / pk.B, b = n - r * pk.B, H = a.H, W = a.W;
+            int sy, sx;                                        // source coordinates in the un-rotated image (as k_pack_input)
+            switch (r) {
+                case 0: sy = yc; sx = xc; break;
+                case 1: sy = xc; sx = W - 1 - yc; break;
+                case 2: sy = H - 1 - yc; sx = W - 1 - xc; break;
+                default: sy = H - 1 - xc; sx = yc; break;
             }
+#pragma unroll
+            for (int c = 0; c < 3; ++c) f32v[it][c] = pk.src[(((long long)b * pk.C + (c < pk.C ? c : 0)) * H + sy) * W + sx];
+        } else {
+            raw[it] = *reinterpret_cast<const u32x2_t*>(src + ((long long)(n * a.H + yc) * a.W + xc) * a.src0.cs);
         }
-        *reinterpret_cast<u32x2_t*>(smem + e * 8) = v;
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * CT_THREADS;
+        u32x2_t v = {0u, 0u};
+        if (ok[it]) {
+            if constexpr (PACK) {
+                h16 c4[3];
+#pragma unroll
+                for (int c = 0; c < 3; ++c) c4[c] = c < pk.C ? (h16)f32v[it][c] : (h16)0.f;
+                v[0] = (unsigned)__builtin_bit_cast(unsigned short, c4[0]) | ((unsigned)__builtin_bit_cast(unsigned short, c4[1]) << 16);
+                v[1] = (unsigned)__builtin_bit_cast(unsigned short, c4[2]);
+            } else v = raw[it];
+        }
+        if (e < HH * HW + 1) *reinterpret_cast<u32x2_t*>(smem + e * 8) = v;
     }
     __syncthreads();
+    if constexpr (PACK) {
+        // the packed rows of this block's own pixels: cpad / 8 pieces of 16 bytes per pixel (piece 0 = the halo entry, the rest zeros),
+        // consecutive lanes = consecutive pieces: every store instruction covers whole, contiguous pixels
+        const int ppx = pk.cpad >> 3;
+        for (int e = tid; e < 16 * 64 * ppx; e += CT_THREADS) {
+            const int p = e / ppx, piece = e - p * ppx;
+            const int ty = p >> 6, tx = p & 63;
+            u32x4_t o = {0u, 0u, 0u, 0u};
+            if (piece == 0) {
+                const u32x2_t v = *reinterpret_cast<const u32x2_t*>(smem + (((ty + padT) * HW + tx + padL) << 3));
+                o[0] = v[0]; o[1] = v[1];
+            }
+            *reinterpret_cast<u32x4_t*>((h16*)pk.dst.p + ((long long)(n * a.H + y0 + ty) * a.W + x0 + tx) * pk.dst.cs + pk.dst.co + piece * 8) = o;
+        }
+    }
     constexpr int OSTR = MT * 64 + 16;
     char* reg = smem + (((HH * HW + 1) * 8 + 15) & ~15) + wave * (32 * OSTR);
     const int npc = a.M >> 3;
@@ -168,6 +195,9 @@ bool conv_thin_eligible(const ssdn_conv_args* a) {
     if ((a->H & 15) || (a->W & 63) || (a->M & 7) || a->Mpad > 64 || a->Mpad < 32) return false;
     if (a->src0.cs < 4 || (a->src0.cs & 3) || (a->src0.co & 3)) return false;      // 8-byte pixel heads
     unsigned long long map; int dy0;
+    int pt, pb, pl, pr;
+    thin_pads(a, &pt, &pb, &pl, &pr);
+    if ((16 + pt + pb) * (64 + pl + pr) + 1 > 6 * CT_THREADS) return false;
     return thin_window(a, &map, &dy0);
 }
 
