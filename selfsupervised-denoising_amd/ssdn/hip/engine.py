@@ -150,7 +150,7 @@ class DeviceNet:
         for first, end in windows:
             for d in (flush_at, last):
                 for k in d:
-                    if first <= d[k] < end:
+                    if first <= d[k] < end and (CHAIN_POSTPONES is None or k in CHAIN_POSTPONES):
                         d[k] = end
         out, names, pending = [], [], {k: [] for k in range(len(buckets))}
         pending_small = {k: [] for k in range(len(buckets))}
@@ -305,6 +305,10 @@ MAIN_LANE_WGRADS = ("encode_block_1.0", "encode_block_1.2")
 # True: when the merged small-layer launches of two gradient buckets end up next to each other in the list, the first bucket's
 # reductions go between them (two k_wgrad_multi launches); False: one launch for both, then both buckets' reductions.
 SPLIT_SMALL_RUNS = True
+# Gradient buckets whose side-lane records are moved behind a run of chainable main-lane ops (None: all).  Moving the decoder
+# bucket's merged weight-gradient launch behind the whole run makes ONE chain of 12 ops, but that launch then waits for the end of the
+# chain; leaving it where the bucket's last gradient appears makes two chains (3 + 9 ops) and starts it ~100 us earlier.
+CHAIN_POSTPONES = (2,)          # measured (tools/ab_lanes.py, same process): all buckets 1.975 ms per step, the encoder bucket only 1.959, none 1.965
 
 STYLE = {"gauss": 0, "poisson": 1}
 MODE = {"known": 0, "const": 1, "var": 2}
