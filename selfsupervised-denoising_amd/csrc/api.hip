@@ -6,6 +6,8 @@
 #include <cstdlib>
 
 static thread_local char g_err[512] = "";
+thread_local hipEvent_t g_ssdn_stop_event = nullptr;
+thread_local bool g_ssdn_stop_used = false;
 
 int ssdn_set_error(const char* fmt, ...) {
     va_list ap;
@@ -171,11 +173,20 @@ static const unsigned g_lane_deps[SSDN_NLANES] = {0u, 1u << 0, (1u << 0) | (1u <
 
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     hipStream_t lane_s[SSDN_NLANES] = {(hipStream_t)stream, nullptr, nullptr, nullptr};
+    g_ssdn_stop_event = nullptr;                                   // (an earlier call may have left through an error path)
     // dirty[s][d]: lane s has enqueued work that lane d (which depends on s) has not been ordered after yet
     bool dirty[SSDN_NLANES][SSDN_NLANES] = {}, used[SSDN_NLANES] = {true, false, false, false};
     for (int d = 1; d < SSDN_NLANES; ++d) dirty[0][d] = true;   // whatever the caller enqueued before this list
     static const bool one_lane = ssdn_tuning_env("SSDN_ONE_LANE") != nullptr;   // tuning / debugging aid
     LaneSet* LS = nullptr;
+    // cover[s]: an event that stands for everything lane s has enqueued so far (covered[s]); a kernel whose completion the NEXT op of the
+    // list (another lane) waits for carries one as its stop event (SSDN_LAUNCH): the dependent lane waits without a hipEventRecord
+    hipEvent_t cover[SSDN_NLANES] = {nullptr, nullptr, nullptr, nullptr};
+    bool covered[SSDN_NLANES] = {false, false, false, false};
+    bool has_side = false;
+    static const bool no_stop = ssdn_tuning_env("SSDN_NO_STOP_EVENTS") != nullptr;      // A/B aid, read once
+    for (int i = 0; i < n && !one_lane; ++i) has_side = has_side || ops[i].lane > 0;
+    if (has_side && !(LS = lanes_get())) return -1;
     for (int i = 0; i < n; ++i) {
         const void* p = ops[i].args;
         int rc = 0;
@@ -187,15 +198,30 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             for (int l = 1; l < SSDN_NLANES; ++l) lane_s[l] = LS->side[l];
             for (int src = 0; src < SSDN_NLANES; ++src) {
                 if (!((g_lane_deps[lane] >> src) & 1) || !dirty[src][lane]) continue;
-                hipEvent_t e = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
-                SSDN_CHECK_HIP(hipEventRecord(e, lane_s[src]));
-                SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[lane], e, 0));
+                if (!covered[src]) {
+                    cover[src] = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
+                    SSDN_CHECK_HIP(hipEventRecord(cover[src], lane_s[src]));
+                    covered[src] = true;
+                }
+                SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[lane], cover[src], 0));
                 dirty[src][lane] = false;
             }
         }
         for (int d = 0; d < SSDN_NLANES; ++d) dirty[lane][d] = true;
         used[lane] = true;
+        covered[lane] = false;
         hipStream_t s = lane_s[lane];
+        // arm(j): the op (or merged run) being launched ends at list index j - 1; if the op at j runs on a lane that is ordered after
+        // this one, the launch carries a stop event (attaching one to EVERY kernel costs each ~5 us of completion handling)
+        bool armed = false;
+        auto arm = [&](int j) {
+            if (!has_side || no_stop || j >= n) return;
+            const int lj = one_lane ? 0 : ops[j].lane;
+            if (lj == lane || lj < 0 || lj >= SSDN_NLANES || !((g_lane_deps[lj] >> lane) & 1)) return;
+            g_ssdn_stop_event = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
+            g_ssdn_stop_used = false;
+            armed = true;
+        };
         switch (ops[i].type) {
             case SSDN_OP_PACK_INPUT: {   // ... directly followed by the thin first layer that reads it: one launch (conv_thin.hip)
                 const bool next_conv = i + 1 < n && ops[i + 1].type == SSDN_OP_CONV && ops[i + 1].args && (one_lane ? 0 : ops[i + 1].lane) == lane;
@@ -208,15 +234,16 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_CONV: {    // a run of consecutive small-image ops on the same lane is one launch (conv_chain.hip)
                 const int m = chain_len(ops + i, n - i, one_lane);
                 if (m < 0) return -1;
+                arm(i + (m > 1 ? m : 1));
                 if (m > 1) { rc = launch_chain(ops + i, m, one_lane, s); i += m - 1; }
                 else rc = launch_conv((const ssdn_conv_args*)p, s);
                 break;
             }
             case SSDN_OP_POOL_FWD: rc = launch_pool_fwd((const ssdn_pool_args*)p, s); break;
-            case SSDN_OP_POOL_BWD: rc = launch_pool_bwd((const ssdn_pool_args*)p, s); break;
-            case SSDN_OP_UPSUM_BWD: rc = launch_upsum_bwd((const ssdn_upsum_args*)p, s); break;
+            case SSDN_OP_POOL_BWD: arm(i + 1); rc = launch_pool_bwd((const ssdn_pool_args*)p, s); break;
+            case SSDN_OP_UPSUM_BWD: arm(i + 1); rc = launch_upsum_bwd((const ssdn_upsum_args*)p, s); break;
             case SSDN_OP_UNROT_FWD: rc = launch_unrot_fwd((const ssdn_unrot_args*)p, s); break;
-            case SSDN_OP_UNROT_BWD: rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
+            case SSDN_OP_UNROT_BWD: arm(i + 1); rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_WGRAD: {   // a run of consecutive small-layer weight-gradient GEMMs on the same lane is one launch
                 static const bool no_merge = ssdn_tuning_env("SSDN_NO_WGRAD_MERGE") != nullptr;      // A/B aid, read once
                 const ssdn_wgrad_args* items[WGRAD_MULTI_MAX];
@@ -248,7 +275,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
                 i += m - 1;
                 break;
             }
-            case SSDN_OP_GRAD_PACK: rc = launch_grad_pack((const ssdn_grad_pack_args*)p, s); break;
+            case SSDN_OP_GRAD_PACK: arm(i + 1); rc = launch_grad_pack((const ssdn_grad_pack_args*)p, s); break;
             case SSDN_OP_HEAD_SSDN: rc = launch_head((const ssdn_head_args*)p, s); break;
             case SSDN_OP_HEAD_FINAL: rc = launch_head_final((const ssdn_head_final_args*)p, s); break;
             case SSDN_OP_SPATIAL_MEAN: rc = launch_spatial_mean((const ssdn_spatial_mean_args*)p, s); break;
@@ -285,6 +312,10 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
                 break;
             }
             default: return ssdn_set_error("op %d: unknown type %d", i, ops[i].type);
+        }
+        if (armed) {
+            if (g_ssdn_stop_used && !rc) { cover[lane] = g_ssdn_stop_event; covered[lane] = true; }   // (the op's last launch carries it)
+            g_ssdn_stop_event = nullptr;
         }
         if (rc) {
             char tmp[400];

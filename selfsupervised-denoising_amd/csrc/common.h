@@ -1,6 +1,7 @@
 // common.h -- shared device helpers for the gfx950 kernels of libssdn_hip.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include "../../include/ssdn_hip.h"
 #include <cstdlib>
@@ -82,6 +83,19 @@ static __device__ __forceinline__ half8 zero_h8() {
     for (int i = 0; i < 8; ++i) z[i] = (h16)0.f;
     return z;
 }
+
+// Launch macro of the kernels whose completion another lane may wait for: when the executor has set a stop event for the op in flight
+// (api.hip), the event rides on the kernel's own completion signal (hipExtLaunchKernelGGL) -- a separate hipEventRecord costs the
+// producing stream a 5-14 us bubble behind every such kernel (a barrier packet the next dispatch queues behind).
+extern thread_local hipEvent_t g_ssdn_stop_event;
+extern thread_local bool g_ssdn_stop_used;
+#define SSDN_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                       \
+    do {                                                                                                                         \
+        if (g_ssdn_stop_event) {                                                                                                 \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, g_ssdn_stop_event, 0, __VA_ARGS__);                 \
+            g_ssdn_stop_used = true;                                                                                             \
+        } else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                \
+    } while (0)
 
 // in-stream profiler (api.hip)
 void prof_begin(int kind, hipStream_t s);

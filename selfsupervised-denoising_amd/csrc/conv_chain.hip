@@ -785,8 +785,8 @@ int launch_chain(const ssdn_op* ops, int n, bool any_lane, hipStream_t s) {
 #ifdef SSDN_TUNING
     trace = (unsigned long long*)ssdn_debug_get_trace();
 #endif
-    if (h.bf) hipLaunchKernelGGL(k_conv_chain<true>, dim3(h.N), dim3(CH_THREADS), h.lds, s, (const ChainArgs*)h.dev, trace);
-    else hipLaunchKernelGGL(k_conv_chain<false>, dim3(h.N), dim3(CH_THREADS), h.lds, s, (const ChainArgs*)h.dev, trace);
+    if (h.bf) SSDN_LAUNCH(k_conv_chain<true>, dim3(h.N), dim3(CH_THREADS), h.lds, s, (const ChainArgs*)h.dev, trace);
+    else SSDN_LAUNCH(k_conv_chain<false>, dim3(h.N), dim3(CH_THREADS), h.lds, s, (const ChainArgs*)h.dev, trace);
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -597,7 +597,7 @@ static int cd_launch(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
     const double flops = 2.0 * px * x.m_cnt * kreal * 9;
     const double bytes = px * (a->c0 * 2.0 / (a->up0 ? 4.0 : 1.0) + a->c1 * 2.0) + px * x.m_cnt * 2.0;
     prof_begin(MT == 3 ? SSDN_PROF_CDMA_MT3 : SSDN_PROF_CDMA_MT21, s);
-    hipLaunchKernelGGL((k_cdma<MT, BF, EPI>), dim3(grid), dim3(256), conv_dma_lds_bytes(MT), s, *a, x);
+    SSDN_LAUNCH((k_cdma<MT, BF, EPI>), dim3(grid), dim3(256), conv_dma_lds_bytes(MT), s, *a, x);
     prof_end(MT == 3 ? SSDN_PROF_CDMA_MT3 : SSDN_PROF_CDMA_MT21, s, flops, bytes);
     return 0;
 }

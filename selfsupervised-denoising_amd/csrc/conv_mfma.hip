@@ -862,7 +862,7 @@ static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x,
     if (a->pool.p && !x.flat) return ssdn_set_error("conv: fused max-pool requested for a launch that does not take the flat path");
     if (a->upsum.p && !x.flat) return ssdn_set_error("conv: fused upsum requested for a launch that does not take the flat path");
     const int grid_all = nblk_y > 1 ? ((grid + 7) / 8) * 8 * nblk_y : grid;
-    hipLaunchKernelGGL((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid_all), dim3(CONV_THREADS), lds, s, *a, x);
+    SSDN_LAUNCH((k_conv<MT, BF, KS, CONV_THREADS>), dim3(grid_all), dim3(CONV_THREADS), lds, s, *a, x);
     prof_end(3 - MT, s, flops, bytes);
     return 0;
 }

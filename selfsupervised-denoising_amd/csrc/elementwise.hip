@@ -146,7 +146,7 @@ int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s) {
     if ((a->C & 7) || (a->H & 1) || (a->W & 1)) return ssdn_set_error("pool: C%%8, H%%2, W%%2 must be 0");
     long long n = (long long)a->N * (a->H / 2) * (a->W / 2) * (a->C / 8);
     if (n >= (1ll << 31)) return ssdn_set_error("k_pool_bwd: too many elements for 32-bit indexing");
-    hipLaunchKernelGGL(k_pool_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    SSDN_LAUNCH(k_pool_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
 
@@ -181,7 +181,7 @@ int launch_upsum_bwd(const ssdn_upsum_args* a, hipStream_t s) {
     if (a->C & 7) return ssdn_set_error("upsum: C%%8 must be 0");
     long long n = (long long)a->N * a->H * a->W * (a->C / 8);
     if (n >= (1ll << 31)) return ssdn_set_error("k_upsum_bwd: too many elements for 32-bit indexing");
-    hipLaunchKernelGGL(k_upsum_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    SSDN_LAUNCH(k_upsum_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
 
@@ -255,7 +255,7 @@ int launch_unrot_bwd(const ssdn_unrot_args* a, hipStream_t s) {
     if (a->C & 7) return ssdn_set_error("unrot: C%%8 must be 0");
     long long n = (long long)4 * a->B * a->P * a->P * (a->C / 8);
     if (n >= (1ll << 31)) return ssdn_set_error("k_unrot_bwd: too many elements for 32-bit indexing");
-    hipLaunchKernelGGL(k_unrot_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    SSDN_LAUNCH(k_unrot_bwd, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
 
@@ -286,7 +286,7 @@ __global__ void k_grad_pack(ssdn_grad_pack_args a) {
 int launch_grad_pack(const ssdn_grad_pack_args* a, hipStream_t s) {
     long long n = (long long)a->N * a->H * a->W;
     if (n >= (1ll << 31)) return ssdn_set_error("k_grad_pack: too many elements for 32-bit indexing");
-    hipLaunchKernelGGL(k_grad_pack, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
+    SSDN_LAUNCH(k_grad_pack, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a);
     return 0;
 }
 

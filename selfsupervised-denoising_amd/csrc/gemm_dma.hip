@@ -309,7 +309,7 @@ static int gd_launch(const ssdn_conv_args* a, hipStream_t s) {
     int cus = ssdn_device_cus();
     if (cus <= 0) cus = 256;
     const int grid = x.ntiles < cus ? x.ntiles : cus;           // persistent: one workgroup per CU (LDS-bound occupancy)
-    hipLaunchKernelGGL((k_gdma<WP, WM, NWP, NWM, BF, EPI>), dim3(grid), dim3(64 * NWP * NWM), LDS, s, *a, x);
+    SSDN_LAUNCH((k_gdma<WP, WM, NWP, NWM, BF, EPI>), dim3(grid), dim3(64 * NWP * NWM), LDS, s, *a, x);
     prof_end(SSDN_PROF_GEMM, s, 2.0 * px * a->M * kreal, px * (a->c0 + a->M) * 2.0);
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;
