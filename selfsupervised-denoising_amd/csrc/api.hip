@@ -222,6 +222,15 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             g_ssdn_stop_used = false;
             armed = true;
         };
+        // the last op of a side lane: the join at the end of the list waits for its stop event
+        auto arm_last = [&](int j) {
+            if (!has_side || no_stop || lane == 0 || armed) return;
+            for (; j < n; ++j)
+                if ((one_lane ? 0 : ops[j].lane) == lane) return;
+            g_ssdn_stop_event = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
+            g_ssdn_stop_used = false;
+            armed = true;
+        };
         switch (ops[i].type) {
             case SSDN_OP_PACK_INPUT: {   // ... directly followed by the thin first layer that reads it: one launch (conv_thin.hip)
                 const bool next_conv = i + 1 < n && ops[i + 1].type == SSDN_OP_CONV && ops[i + 1].args && (one_lane ? 0 : ops[i + 1].lane) == lane;
@@ -261,6 +270,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
                 while (m < WREDUCE_MULTI_MAX && i + m < n && ops[i + m].type == SSDN_OP_WREDUCE && ops[i + m].args &&
                        (one_lane ? 0 : ops[i + m].lane) == lane)
                     items[m] = (const ssdn_wreduce_args*)ops[i + m].args, ++m;
+                arm_last(i + m);
                 rc = m > 1 ? launch_wreduce_multi(items, m, s) : launch_wreduce((const ssdn_wreduce_args*)p, s);
                 i += m - 1;
                 break;
@@ -325,9 +335,11 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     }
     for (int l = 1; l < SSDN_NLANES; ++l) {   // join every side lane back into the caller's stream
         if (!used[l]) continue;
-        hipEvent_t e = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
-        SSDN_CHECK_HIP(hipEventRecord(e, lane_s[l]));
-        SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[0], e, 0));
+        if (!covered[l]) {
+            cover[l] = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
+            SSDN_CHECK_HIP(hipEventRecord(cover[l], lane_s[l]));
+        }
+        SSDN_CHECK_HIP(hipStreamWaitEvent(lane_s[0], cover[l], 0));
     }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return ssdn_set_error("launch error: %s", hipGetErrorString(e));

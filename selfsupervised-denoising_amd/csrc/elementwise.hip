@@ -517,7 +517,7 @@ int launch_wreduce_multi(const ssdn_wreduce_args* const* items, int n, hipStream
     t1.bstart[n] = b1;
     t2.bstart[n] = b2;
     if (b1 > 0) hipLaunchKernelGGL(k_wreduce_partial_multi, dim3(b1), dim3(EW_BLOCK), 0, s, t1);
-    if (b2 > 0) hipLaunchKernelGGL(k_wreduce_multi, dim3(b2), dim3(EW_BLOCK), 0, s, t2);
+    if (b2 > 0) SSDN_LAUNCH(k_wreduce_multi, dim3(b2), dim3(EW_BLOCK), 0, s, t2);
     return 0;
 }
 
@@ -531,7 +531,7 @@ int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s) {
     }
     if (a->Kpad & 3) return ssdn_set_error("wreduce: Kpad must be a multiple of 4");
     long long n = stride / 4 + a->M;
-    hipLaunchKernelGGL(k_wreduce, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a, step);
+    SSDN_LAUNCH(k_wreduce, dim3(ew_grid(n)), dim3(EW_BLOCK), 0, s, *a, step);
     return 0;
 }
 
