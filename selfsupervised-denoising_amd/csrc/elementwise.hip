@@ -539,16 +539,21 @@ int launch_wreduce(const ssdn_wreduce_args* a, hipStream_t s) {
 // ADAM  (train.py:100-107,202): one fused pass over the flat master buffer
 // ------------------------------------------------------------------------------------------------
 // one element of the Adam update (shared by k_adam and k_adam_pack: the two must round identically; explicit fmaf / no re-association)
-static __device__ __forceinline__ float adam_elem(const ssdn_adam_args& a, long long i, float inv_bc2s, float step) {
-    const float g = a.g[i] * a.gscale;
-    const float m = __fmaf_rn(a.b1, a.m[i], __fmul_rn(1.f - a.b1, g));
-    const float v = __fmaf_rn(a.b2, a.v[i], __fmul_rn(__fmul_rn(1.f - a.b2, g), g));
+struct AdamIn { float g, m, v, p; };
+static __device__ __forceinline__ AdamIn adam_load(const ssdn_adam_args& a, long long i) { return AdamIn{a.g[i], a.m[i], a.v[i], a.p[i]}; }
+static __device__ __forceinline__ float adam_apply(const ssdn_adam_args& a, long long i, const AdamIn& q, float inv_bc2s, float step) {
+    const float g = q.g * a.gscale;
+    const float m = __fmaf_rn(a.b1, q.m, __fmul_rn(1.f - a.b1, g));
+    const float v = __fmaf_rn(a.b2, q.v, __fmul_rn(__fmul_rn(1.f - a.b2, g), g));
     a.m[i] = m;
     a.v[i] = v;
     const float den = __fmaf_rn(sqrtf(v), inv_bc2s, a.eps);
-    const float pn = __fsub_rn(a.p[i], __fdiv_rn(__fmul_rn(step, m), den));
+    const float pn = __fsub_rn(q.p, __fdiv_rn(__fmul_rn(step, m), den));
     a.p[i] = pn;
     return pn;
+}
+static __device__ __forceinline__ float adam_elem(const ssdn_adam_args& a, long long i, float inv_bc2s, float step) {
+    return adam_apply(a, i, adam_load(a, i), inv_bc2s, step);
 }
 __global__ void k_adam(ssdn_adam_args a) {
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -561,34 +566,99 @@ __global__ void k_adam(ssdn_adam_args a) {
 // weights lie in its range): the thread that updates a weight also writes its 16-bit images into the MFMA shadows -- the value it
 // just computed, converted exactly as k_wpack converts it (bit-identical shadows; the padding of the shadows is never rewritten, it
 // stays the zeros of the first re-pack).  Saves the re-pack launch after every optimiser step (23 us) and one read of the parameters.
+// Work split: a block owns ONE tile of one layer -- 8 output channels x 48 input channels x all taps -- or 1024 elements of a stretch
+// without shadows (biases, the learnable sigma).  The tile is read in master order (OIHW: runs of 48 x ntaps floats), updated, parked in
+// LDS and written out in SHADOW order: [tap][row][k] runs of 96 bytes for the forward shadows, 16-byte pieces (8 consecutive output
+// channels) for the transposed data-gradient shadows.  (One thread per parameter scattered 2-byte stores over four tensors: 31 us.)
+#define AP_TM 8
+#define AP_TK 48
 struct AdamPackTable {
     ssdn_adam_args a;
     ssdn_wpack_args e[ADAM_PACK_MAX];
     long long w_off[ADAM_PACK_MAX];     // first element of the layer's weight tensor in the Adam range (ascending)
-    int n;
+    int bstart[ADAM_PACK_MAX + 1];      // first block of the layer's tiles
+    int tiles_k[ADAM_PACK_MAX];         // 48-channel tiles per row of tiles
+    long long gap_start[ADAM_PACK_MAX + 2];   // stretches of the range without shadows: [gap_start[g], gap_end[g])
+    long long gap_end[ADAM_PACK_MAX + 2];
+    int gap_bstart[ADAM_PACK_MAX + 3];  // first block of each stretch (after all tile blocks)
+    int n, ngaps;
 };
-__global__ void k_adam_pack(AdamPackTable t) {
+template <int NT>
+static __device__ __forceinline__ void adam_pack_tile(const AdamPackTable& t, int j, int tile, float* lds, float inv_bc2s, float step) {
     const ssdn_adam_args& a = t.a;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    const long long stride = (long long)gridDim.x * blockDim.x;
+    const ssdn_wpack_args& w = t.e[j];
+    const int tk = t.tiles_k[j];
+    const int mo0 = (tile / tk) * AP_TM, k0 = (tile % tk) * AP_TK;
+    const int tid = threadIdx.x;
+    // phase 1: master order; the loads of up to 7 elements of a thread are in flight together (one element at a time was a chain of 14
+    // exposed HBM round trips per thread)
+    constexpr int TOTAL = AP_TM * AP_TK * NT, NIT = (TOTAL + EW_BLOCK - 1) / EW_BLOCK, BATCH = NIT < 7 ? NIT : 7;
+#pragma unroll
+    for (int it0 = 0; it0 < NIT; it0 += BATCH) {
+        AdamIn q[BATCH];
+        long long idx[BATCH];
+        bool ok[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = tid + (it0 + u) * EW_BLOCK;
+            const int mo = e / (AP_TK * NT), r = e - mo * (AP_TK * NT);
+            const int kk = r / NT, tp = r - kk * NT;
+            ok[u] = it0 + u < NIT && e < TOTAL && mo0 + mo < w.M && k0 + kk < w.cin;
+            idx[u] = ok[u] ? t.w_off[j] + ((long long)(mo0 + mo) * w.cin + k0 + kk) * NT + tp : t.w_off[j];
+            q[u] = adam_load(a, idx[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; ++u) {
+            const int e = tid + (it0 + u) * EW_BLOCK;
+            if (it0 + u >= NIT || e >= TOTAL) continue;
+            const int mo = e / (AP_TK * NT), r = e - mo * (AP_TK * NT);
+            const int kk = r / NT, tp = r - kk * NT;
+            lds[(tp * AP_TM + mo) * (AP_TK + 1) + kk] = ok[u] ? adam_apply(a, idx[u], q[u], inv_bc2s, step) : 0.f;
+        }
+    }
+    __syncthreads();
+    // phase 2a: forward shadows, k fastest
+    for (int e = tid; e < NT * AP_TM * AP_TK; e += EW_BLOCK) {
+        const int tp = e / (AP_TM * AP_TK), r = e - tp * (AP_TM * AP_TK);
+        const int mo = r / AP_TK, kk = r - mo * AP_TK;
+        const int m = mo0 + mo, k = k0 + kk;
+        if (m >= w.M || k >= w.cin) continue;
+        const float pn = lds[(tp * AP_TM + mo) * (AP_TK + 1) + kk];
+        ((h16*)w.wf)[((long long)tp * w.Mpad_f + m) * w.Ktot + k] = (h16)pn;
+        if (w.wfc) ((h16*)w.wfc)[wpack_cm(tp, m, k, w.Mpad_f, w.Ktot)] = (h16)pn;
+    }
+    // phase 2b: data-gradient shadows (transposed), output channel fastest
+    if (w.wd) {
+        for (int e = tid; e < NT * AP_TK * AP_TM; e += EW_BLOCK) {
+            const int tp = e / (AP_TK * AP_TM), r = e - tp * (AP_TK * AP_TM);
+            const int kk = r / AP_TM, mo = r - kk * AP_TM;
+            const int m = mo0 + mo, k = k0 + kk;
+            if (m >= w.M || k >= w.cin || k >= w.Mpad_d || m >= w.Kd) continue;   // (the shadow may cover fewer input slots: decode_block_1.0's image channels need no gradient)
+            const float pn = lds[(tp * AP_TM + mo) * (AP_TK + 1) + kk];
+            ((unsigned short*)w.wd)[((long long)tp * w.Mpad_d + k) * w.Kd + m] = f2bf(pn);
+            if (w.wdc) ((unsigned short*)w.wdc)[wpack_cm(tp, k, m, w.Mpad_d, w.Kd)] = f2bf(pn);
+        }
+    }
+}
+__global__ void k_adam_pack(AdamPackTable t) {
+    __shared__ float lds[9 * AP_TM * (AP_TK + 1)];
+    const ssdn_adam_args& a = t.a;
     const float inv_bc2s = 1.f / sqrtf(a.bc2);
     const float step = a.lr / a.bc1;
-    for (; i < a.n; i += stride) {
-        const float pn = adam_elem(a, i, inv_bc2s, step);
+    const int b = blockIdx.x;
+    if (b < t.bstart[t.n]) {
         int j = 0;
-        while (j + 1 < t.n && i >= t.w_off[j + 1]) ++j;
-        const ssdn_wpack_args& w = t.e[j];
-        const long long off = i - t.w_off[j];
-        if (off < 0 || off >= (long long)w.M * w.cin * w.ntaps) continue;           // a bias (or a tensor without shadows)
-        const int tp = (int)(off % w.ntaps);
-        const int ci = (int)((off / w.ntaps) % w.cin);
-        const int mo = (int)(off / ((long long)w.ntaps * w.cin));
-        const int k = ci;                                                               // slot of input channel ci (k_to_cin is the identity on real slots)
-        ((h16*)w.wf)[((long long)tp * w.Mpad_f + mo) * w.Ktot + k] = (h16)pn;
-        if (w.wfc) ((h16*)w.wfc)[wpack_cm(tp, mo, k, w.Mpad_f, w.Ktot)] = (h16)pn;
-        if (w.wd && k < w.Mpad_d && mo < w.Kd) {       // (the data-gradient shadow may cover fewer input slots: decode_block_1.0's image channels need no gradient)
-            ((unsigned short*)w.wd)[((long long)tp * w.Mpad_d + k) * w.Kd + mo] = f2bf(pn);
-            if (w.wdc) ((unsigned short*)w.wdc)[wpack_cm(tp, k, mo, w.Mpad_d, w.Kd)] = f2bf(pn);
+        while (j + 1 < t.n && b >= t.bstart[j + 1]) ++j;
+        if (t.e[j].ntaps == 9) adam_pack_tile<9>(t, j, b - t.bstart[j], lds, inv_bc2s, step);
+        else adam_pack_tile<1>(t, j, b - t.bstart[j], lds, inv_bc2s, step);
+    } else {
+        int g = 0;
+        while (g + 1 < t.ngaps && b >= t.gap_bstart[g + 1]) ++g;
+        const long long first = t.gap_start[g] + (long long)(b - t.gap_bstart[g]) * (EW_BLOCK * 4) + threadIdx.x;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const long long i = first + u * EW_BLOCK;
+            if (i < t.gap_end[g]) adam_elem(a, i, inv_bc2s, step);
         }
     }
 }
@@ -600,7 +670,7 @@ int adam_pack_fusable(const ssdn_adam_args* a, const ssdn_wpack_args* const* ite
         const ssdn_wpack_args* w = items[i];
         const long long off = w->w - a->p;
         if (w->w < a->p || off + (long long)w->M * w->cin * w->ntaps > a->n || off <= prev) return 0;
-        if (w->c0 + w->c1_real != w->cin) return 0;
+        if (w->c0 + w->c1_real != w->cin || (w->ntaps != 1 && w->ntaps != 9)) return 0;
         prev = off;
     }
     return 1;
@@ -609,10 +679,31 @@ int launch_adam_pack(const ssdn_adam_args* a, const ssdn_wpack_args* const* item
     AdamPackTable t;
     t.a = *a;
     t.n = n;
-    for (int i = 0; i < n; ++i) { t.e[i] = *items[i]; t.w_off[i] = items[i]->w - a->p; }
-    int g = ew_grid(a->n);
-    if (g > 2048) g = 2048;
-    hipLaunchKernelGGL(k_adam_pack, dim3(g), dim3(EW_BLOCK), 0, s, t);
+    int blocks = 0, ng = 0;
+    long long pos = 0;
+    auto gap = [&](long long start, long long end) {
+        if (end <= start) return;
+        t.gap_start[ng] = start; t.gap_end[ng] = end;
+        ++ng;
+    };
+    for (int i = 0; i < n; ++i) {
+        t.e[i] = *items[i];
+        t.w_off[i] = items[i]->w - a->p;
+        t.bstart[i] = blocks;
+        t.tiles_k[i] = (items[i]->cin + AP_TK - 1) / AP_TK;
+        blocks += ((items[i]->M + AP_TM - 1) / AP_TM) * t.tiles_k[i];
+        gap(pos, t.w_off[i]);
+        pos = t.w_off[i] + (long long)items[i]->M * items[i]->cin * items[i]->ntaps;
+    }
+    t.bstart[n] = blocks;
+    gap(pos, a->n);
+    t.ngaps = ng;
+    for (int g = 0; g < ng; ++g) {
+        t.gap_bstart[g] = blocks;
+        blocks += (int)((t.gap_end[g] - t.gap_start[g] + EW_BLOCK * 4 - 1) / (EW_BLOCK * 4));
+    }
+    t.gap_bstart[ng] = blocks;
+    if (blocks > 0) hipLaunchKernelGGL(k_adam_pack, dim3(blocks), dim3(EW_BLOCK), 0, s, t);
     return 0;
 }
 int launch_adam(const ssdn_adam_args* a, hipStream_t s) {
