@@ -1,0 +1,60 @@
+"""CPU test of the backward list the engine emits (ssdn/hip/engine.py::DeviceNet._group_reductions): the planner's list re-ordered for the
+merged launches (slab reductions per gradient bucket, small-layer weight gradients per bucket, chained main-lane runs, main-lane weight
+gradients).  Legal re-orderings only DELAY side-lane work; these are the invariants the executor's lane semantics rely on."""
+import pytest
+
+from ssdn.hip import engine as E
+from ssdn.hip.dp import bucket_layers
+from ssdn.hip.graph import NetPlan
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P", [(3, 9, True, 32, 64), (3, 3, False, 4, 64), (1, 2, True, 2, 32), (3, 9, True, 16, 128)])
+def test_backward_list_order_invariants(cin, cout, bs, B, P):
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=256)
+    recs = [(op.type, i) for i, op in enumerate(plan.bwd)]               # the "argument struct" of record i is its planner index
+    out, names = E.DeviceNet._group_reductions(plan, recs)
+    assert len(out) == len(recs) == len(names)
+    pos = {r[1]: k for k, r in enumerate(out)}
+    assert sorted(pos) == list(range(len(recs))), "the emitted list is a permutation of the planner's"
+    side = lambda i: plan.bwd[i].type in ("wgrad", "wreduce")            # noqa: E731
+    main_lane = lambda k: (len(out[k]) > 2 and out[k][2] == 0) or not side(out[k][1])   # noqa: E731
+    # 1. main-lane ops keep their order
+    mains = [i for i in range(len(recs)) if not side(i)]
+    assert [pos[i] for i in mains] == sorted(pos[i] for i in mains)
+    # 2. a side-lane op is only ever delayed: it stays behind every main-lane op that preceded it in the planner's list
+    last_main = -1
+    for i in range(len(recs)):
+        if not side(i):
+            last_main = i
+        elif last_main >= 0:
+            assert pos[i] > pos[last_main], "op %d (%s %s) moved in front of its producer" % (i, plan.bwd[i].type, plan.bwd[i].a["layer"])
+    # 3. every reduction follows all weight-gradient launches of its layer, and `names` marks exactly the reductions
+    for i, op in enumerate(plan.bwd):
+        if op.type == "wreduce":
+            assert names[pos[i]] == op.a["layer"]
+            for j, oj in enumerate(plan.bwd):
+                if oj.type == "wgrad" and oj.a["layer"] == op.a["layer"]:
+                    assert pos[j] < pos[i]
+        else:
+            assert names[pos[i]] is None
+    # 4. a gradient bucket's reductions are one consecutive run (the executor merges it into two launches)
+    buckets = bucket_layers(plan.layers)
+    for b in buckets:
+        ks = sorted(pos[i] for i, op in enumerate(plan.bwd) if op.type == "wreduce" and op.a["layer"] in b)
+        if ks:
+            assert ks == list(range(ks[0], ks[0] + len(ks)))
+    # 5. weight gradients sent to the main lane come after the last data-gradient launch of their bucket, in front of its reductions
+    for i, op in enumerate(plan.bwd):
+        if op.type == "wgrad" and op.a["layer"] in E.MAIN_LANE_WGRADS:
+            assert out[pos[i]][2] == 0
+            assert all(pos[j] < pos[i] for j in mains if j < max(k for k, o in enumerate(plan.bwd) if o.type == "wgrad" and o.a["layer"] == op.a["layer"]))
+    # 6. the chainable main-lane ops of the encoder end form one run without side-lane records in between
+    if P == 64 and B * (4 if bs else 1) >= 16:
+        chain = [i for i, op in enumerate(plan.bwd)
+                 if (op.type == "conv" and op.a["role"] == "dgrad" and len(op.a["taps"]) == 9 and op.a["H"] * op.a["W"] <= 64) or
+                 (op.type == "pool_bwd" and (op.a["H"] // 2) * (op.a["W"] // 2) <= 64)]
+        assert len(chain) >= 9
+        tail = chain[3:]                                                 # (the decoder bucket's merged launch stays behind the third op)
+        ks = [pos[i] for i in tail]
+        between = [k for k in range(ks[0], ks[-1] + 1) if k not in ks]
+        assert all(main_lane(k) for k in between), "side-lane records inside the chained run"
