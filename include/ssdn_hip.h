@@ -270,7 +270,8 @@ typedef struct ssdn_wpack_args {
 /* ---- SSDN_OP_GRAD_PACK ----------------------------------------------------------------------
  * fp32 NCHW gradient w.r.t. net_out -> bf16 NHWC [N,H,W,cpad] (zero padded channels).  bf16 keeps the fp32 exponent
  * range, so there is NO loss scaling; scale_out[0] = scale_out[1] = 1 is written for SSDN_OP_WREDUCE's inv_scale input.
- * gmax (float bits of max |g|, written by the loss kernels with atomicMax) is kept as an overflow / NaN sentinel. */
+ * gmax (float bits of max |g|, written by the loss kernels with atomicMax) is kept as an overflow / NaN sentinel: a running maximum --
+ * the host clears it (SSDN_OP_ZERO) when it wants a per-step figure. */
 typedef struct ssdn_grad_pack_args {
     const float* g; /* [N,C,H,W] */
     ssdn_view dst;

@@ -369,10 +369,8 @@ class DenoiserEngine:
         B, Cn, H, W = self.B, self.C, self.H, self.W
         out32 = self.main.tensor("out32")
         g32 = _ptr(self.main.tensor("g32")) if want_grad else None
-        if want_grad:
-            recs.append(("zero", L.ZeroArgs(_ptr(self.main.tensor("gmax")), 16)))
-            if self.sigma is not None:
-                recs.append(("zero", L.ZeroArgs(_ptr(self.sigma.tensor("gmax")), 16)))
+        # (gmax, the max-|gradient| sentinel the loss kernels fold into with atomicMax, is a RUNNING maximum since the buffers were created:
+        #  clearing its 16 bytes every step was a launch of its own in the serial stretch between the forward and the backward pass)
         if self.pipeline == "ssdn":
             est_ptr = None
             if self.mode == "var":
