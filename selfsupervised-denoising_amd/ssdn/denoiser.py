@@ -312,7 +312,8 @@ class Denoiser(nn.Module):
         from ssdn.hip import dp
         out = self._run(data, clone=False, bridge=False)
         eng = self._last_train_engine
-        scale = dp.exchange_step(lambda ex: eng.backward(exchange=ex), self.flat_grad, exchange)
+        from ssdn.hip import engine as _engine
+        scale = dp.exchange_step(lambda ex: eng.backward(exchange=ex, defer_tail=ex is None and _engine.DEFER_TAIL), self.flat_grad, exchange)
         self.optimizer_step(lr, scale)
         return out
 

@@ -72,6 +72,14 @@ class DeviceNet:
         self.fwd = OpList([self._mat(op) for op in plan.fwd])
         self._bwd_recs, self._bwd_layers = self._group_reductions(plan, [self._mat(op) for op in plan.bwd])
         self.bwd = OpList(self._bwd_recs, lanes=True)
+        # the last gradient bucket's slab reductions close the list: a training step may run them in front of its optimiser launch
+        # instead (DeviceEngine.backward(defer_tail=True)): [weight-gradient lane: wait for the main lane's last launch, two
+        # reduction launches] -> join -> Adam becomes join -> reductions -> Adam on ONE stream (one cross-lane hop less in the serial tail)
+        ntail = 0
+        while ntail < len(self._bwd_recs) and self._bwd_recs[len(self._bwd_recs) - 1 - ntail][0] == "wreduce":
+            ntail += 1
+        self.tail_recs = [(r[0], r[1]) for r in self._bwd_recs[len(self._bwd_recs) - ntail:]] if 0 < ntail < len(self._bwd_recs) else []
+        self.bwd_head = OpList(self._bwd_recs[:len(self._bwd_recs) - len(self.tail_recs)], lanes=True) if self.tail_recs else None
         self.pack = OpList([self._mat(op) for op in plan.pack])
 
     def bwd_with_events(self, buckets, events):
@@ -305,6 +313,8 @@ MAIN_LANE_WGRADS = ("encode_block_1.0", "encode_block_1.2")
 # True: when the merged small-layer launches of two gradient buckets end up next to each other in the list, the first bucket's
 # reductions go between them (two k_wgrad_multi launches); False: one launch for both, then both buckets' reductions.
 SPLIT_SMALL_RUNS = True
+# Denoiser.train_step without a gradient exchange leaves the last bucket's slab reductions to the optimiser call (DeviceEngine.backward)
+DEFER_TAIL = True
 # Gradient buckets whose side-lane records are moved behind a run of chainable main-lane ops (None: all).  Moving the decoder
 # bucket's merged weight-gradient launch behind the whole run makes ONE chain of 12 ops, but that launch then waits for the end of the
 # chain; leaving it where the bucket's last gradient appears makes two chains (3 + 9 ops) and starts it ~100 us earlier.
@@ -356,7 +366,10 @@ class DenoiserEngine:
         self.zero_buf = torch.zeros((8,), dtype=torch.int32, device=device)   # unused gmax sink for eval
         self._adam_args = None
         self.ops_loss = OpList(self._loss_ops(want_grad=train))
-        self.ops_opt = OpList(self._opt_ops()) if train else None
+        opt_recs = self._opt_ops() if train else None          # (both lists share the argument structs adam() updates)
+        self.ops_opt = OpList(opt_recs) if train else None
+        self.ops_opt_tail = OpList(self.main.tail_recs + opt_recs) if train and self.main.tail_recs else None
+        self._tail_pending = False
 
     # ---- op construction -----------------------------------------------------------------------------------
     def _gmax(self, net: Optional[DeviceNet]):
@@ -432,10 +445,19 @@ class DenoiserEngine:
         s = current_stream() if stream is None else stream
         self.main.fwd.run(s)
 
-    def backward(self, stream=None, exchange=None):
+    def backward(self, stream=None, exchange=None, defer_tail=False):
         """Enqueue the backward pass.  exchange (ssdn.hip.dp.GradExchange, overlapped): the main net's list then carries one
-        event record per gradient bucket; the last bucket (sigma estimator / learnable sigma) is marked after its own list."""
+        event record per gradient bucket; the last bucket (sigma estimator / learnable sigma) is marked after its own list.
+        defer_tail (single-GPU training step only): the last bucket's slab reductions are left to the NEXT adam() call, which runs
+        them in front of the optimiser launch -- the flat gradient is incomplete until then."""
         s = current_stream() if stream is None else stream
+        if defer_tail and exchange is None and self.ops_opt_tail is not None:
+            self.main.bwd_head.run(s)
+            if self.sigma is not None:
+                self.sigma.bwd.run(s)
+            self._tail_pending = True
+            return
+        self._tail_pending = False
         if exchange is not None and exchange.overlapped:
             from .dp import bucket_layers
             if getattr(self, "_bwd_ev_key", None) != id(exchange):
@@ -455,4 +477,8 @@ class DenoiserEngine:
         for a in self._adam_args:
             a.lr, a.bc1, a.bc2, a.gscale = lr, 1.0 - 0.9 ** step, 1.0 - 0.99 ** step, gscale
         s = current_stream() if stream is None else stream
+        if self._tail_pending:                # (the deferred reductions of the last bucket, then the optimiser launch)
+            self._tail_pending = False
+            self.ops_opt_tail.run(s)
+            return
         self.ops_opt.run(s)                   # optimiser step + re-pack of the MFMA shadows (one launch per network)

@@ -1,31 +1,30 @@
-"""Same-process A/B of lane assignments of the backward list (engine.MAIN_LANE_WGRADS) on the bench workload."""
+"""Same-process A/B of an engine / planner constant on the bench workload (edit VARIANTS and the line that applies a variant: engine.MAIN_LANE_WGRADS, SPLIT_SMALL_RUNS, CHAIN_POSTPONES, DEFER_TAIL ... were all decided with this tool)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [os.path.join(ROOT, "selfsupervised-denoising_amd"), ROOT]
 import torch
 import bench as B
 from ssdn.hip import engine as E
-from ssdn.hip import graph as G
 from ssdn.denoiser import Denoiser
 from ssdn.datasets import DevicePatchStream, NoisyDataset
 from ssdn.params import NoiseAlgorithm
 
 dev = torch.device("cuda", 0)
-VARIANTS = [0, 128, 96, 160]
+VARIANTS = [True, False]
 nd = NoisyDataset(None, "gauss25", NoiseAlgorithm.SELFSUPERVISED_DENOISING, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
 g = torch.Generator().manual_seed(1)
 u8 = [torch.randint(0, 256, (32, 3, 64, 64), generator=g, dtype=torch.uint8).pin_memory() for _ in range(4)]
 idx = torch.arange(32)
 runs = {}
 for v in VARIANTS:
-    G.MID_WGRAD_CUS = v
     torch.manual_seed(0)
     d = Denoiser(B.make_cfg(), device=str(dev))
     d.train()
     stream = DevicePatchStream(None, nd, dev, seed=1).attach(d)
     state = {"pending": stream.upload(u8[0])}
 
-    def step(i, d=d, stream=stream, state=state):
+    def step(i, d=d, stream=stream, state=state, v=v):
+        E.DEFER_TAIL = v
         cur, state["pending"] = state["pending"], stream.upload(u8[(i + 1) % 4])
         d.train_step(stream.prepare(cur, idx), 3e-4, None)
     for i in range(20):
@@ -46,6 +45,6 @@ for rnd in range(4):
         torch.cuda.synchronize()
         res[v].append(1e3 * (time.perf_counter() - t0) / N)
 for v in VARIANTS:
-    print("mid wgrad cus %s: ms/step %s  median %.4f" % (v, [round(x, 4) for x in res[v]], sorted(res[v])[len(res[v]) // 2]))
+    print("deferred tail reductions %s: ms/step %s  median %.4f" % (v, [round(x, 4) for x in res[v]], sorted(res[v])[len(res[v]) // 2]))
 w = [runs[v][1].flat.clone() for v in VARIANTS]
 print("weights identical across variants:", all(torch.equal(w[0], x) for x in w[1:]))
