@@ -463,7 +463,8 @@ int ssdn_conv_fuses_unrot(const ssdn_conv_args* a);
  *   - a tensor read by an op is either written by an earlier op of the run (same p and cs, a channel window of what was written, same
  *     shape) or written by no op of the run; every output is still written to HBM.
  * The result is bit-identical to one launch per op.  ssdn_chain_len returns how many ops of the prefix of ops[0..n) run as one launch
- * (0 = none, else >= 2; at most 12); ssdn_conv_set_chain(0) switches the merging off (test aid), (1) on (default). */
+ * (0 = none, else >= 2; at most 12; host code only, usable without a GPU); ssdn_conv_set_chain(0) switches the merging off (test
+ * aid; also the folding of SSDN_OP_PACK_INPUT into the first layer's launch), (1) on (default). */
 int ssdn_chain_len(const ssdn_op* ops, int n);
 int ssdn_conv_set_chain(int on);
 

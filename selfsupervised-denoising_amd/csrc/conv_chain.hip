@@ -764,11 +764,18 @@ int chain_len(const ssdn_op* ops, int n, bool any_lane) {
     if (chain_lookup(ops, n, any_lane, &h)) return -1;
     return h.len;
 }
+// (the query plans without touching a device -- no cache, no table upload: usable without a GPU)
 extern "C" int ssdn_chain_len(const ssdn_op* ops, int n) {
     if (!ops || n < 0) return ssdn_set_error("conv chain: bad arguments");
     for (int i = 0; i < n; ++i)
         if (!ops[i].args) return ssdn_set_error("conv chain: null args in op %d", i);
-    return chain_len(ops, n, false);
+    if (!g_chain_on || n < 2 || ops[0].type != SSDN_OP_CONV) return 0;
+    int m = 0;
+    while (m < n && m < CH_MAX_LAYERS && (ops[m].type == SSDN_OP_CONV || ops[m].type == SSDN_OP_POOL_BWD) && ops[m].lane == ops[0].lane) ++m;
+    ChainArgs host;
+    for (int len = m; len >= 2; --len)
+        if (chain_build(ops, len, &host)) return len;
+    return 0;
 }
 
 int launch_chain(const ssdn_op* ops, int n, bool any_lane, hipStream_t s) {
