@@ -464,7 +464,8 @@ int ssdn_conv_fuses_unrot(const ssdn_conv_args* a);
  *     shape) or written by no op of the run; every output is still written to HBM.
  * The result is bit-identical to one launch per op.  ssdn_chain_len returns how many ops of the prefix of ops[0..n) run as one launch
  * (0 = none, else >= 2; at most 12; host code only, usable without a GPU); ssdn_conv_set_chain(0) switches the merging off (test
- * aid; also the folding of SSDN_OP_PACK_INPUT into the first layer's launch), (1) on (default). */
+ * aid; also the folding of SSDN_OP_PACK_INPUT into the first layer's launch and of the narrow fp32-output 1x1 layer into the launch of
+ * the 96-channel 1x1 layer in front of it), (1) on (default). */
 int ssdn_chain_len(const ssdn_op* ops, int n);
 int ssdn_conv_set_chain(int on);
 

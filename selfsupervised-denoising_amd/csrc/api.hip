@@ -243,8 +243,12 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_CONV: {    // a run of consecutive small-image ops on the same lane is one launch (conv_chain.hip)
                 const int m = chain_len(ops + i, n - i, one_lane);
                 if (m < 0) return -1;
-                arm(i + (m > 1 ? m : 1));
+                // ... and the narrow net_out layer directly behind the 96-channel 1x1 layer rides in that layer's launch (gemm_dma.hip)
+                const bool pair = m <= 1 && i + 1 < n && ops[i + 1].type == SSDN_OP_CONV && ops[i + 1].args && (one_lane ? 0 : ops[i + 1].lane) == lane &&
+                                  chain_merging_on() && conv_pair_fusable((const ssdn_conv_args*)p, (const ssdn_conv_args*)ops[i + 1].args);
+                arm(i + (m > 1 ? m : (pair ? 2 : 1)));
                 if (m > 1) { rc = launch_chain(ops + i, m, one_lane, s); i += m - 1; }
+                else if (pair) { rc = launch_gemm_dma_with_next((const ssdn_conv_args*)p, (const ssdn_conv_args*)ops[i + 1].args, s); ++i; }
                 else rc = launch_conv((const ssdn_conv_args*)p, s);
                 break;
             }

@@ -153,5 +153,8 @@ bool conv_pack_fusable(const ssdn_pack_input_args* pk, const ssdn_conv_args* a);
 bool gemm_dma_eligible(const ssdn_conv_args* a);
 int gemm_dma_lds_bytes(const ssdn_conv_args* a);
 int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s);
+bool gemm_dma_fuses_next(const ssdn_conv_args* a, const ssdn_conv_args* b);   // the narrow 1x1 layer b behind the 96-channel 1x1 layer a: one launch
+int launch_gemm_dma_with_next(const ssdn_conv_args* a, const ssdn_conv_args* b, hipStream_t s);
+bool conv_pair_fusable(const ssdn_conv_args* a, const ssdn_conv_args* b);     // conv_mfma.hip: launch_conv would route `a` to k_gdma and b can ride along
 extern "C" int ssdn_device_cus(void);
 int wgrad_lds_bytes(const ssdn_wgrad_args* a);

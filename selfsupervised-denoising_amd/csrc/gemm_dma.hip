@@ -22,6 +22,12 @@ struct GdAux {
     int nch;      // Ktot / 32
     int ntiles;   // pixel tiles of TP
     int lp;       // fused UNROT_BWD: log2 of the image side
+    // EPI bit 2: the launch is ALSO the following narrow 1x1 layer on its own output (the 9-channel net_out layer behind the 96-channel
+    // one): out32[n][m][pixel] = [lrelu](bias4[m] + sum_k w4[m][k] * out(pixel, k)), fp32 NCHW, from the rounded 16-bit tile in LDS
+    const h16* w4;      // packed [1][32][96]
+    const float* b4;    // or NULL
+    float* out32;
+    int M4, act4, HW;
 };
 
 __device__ __forceinline__ void gd_dma16(unsigned lds_addr, int voff, u32x4_t rs, int soff) {
@@ -52,6 +58,7 @@ __device__ __forceinline__ void gd_wait_groups(int n) {
 }  // namespace
 
 // wave grid NWP (pixels) x NWM (channels); a wave owns WP x 32 pixels and WM x 32 output channels.  EPI bit 0: LeakyReLU' mask;
+// bit 2: the next narrow 1x1 layer computed from the output tile (GdAux.w4);
 // bit 1: fused SSDN_OP_UNROT_BWD (the 96-channel block r of a pixel goes, times LeakyReLU', to its place in rotation r's tensor).
 // PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the two operand rings run on as one chunk stream
 // across tile boundaries, so the loads of tile i+1 are in flight while tile i is converted and stored (the epilogue has its own
@@ -68,7 +75,8 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     constexpr int EG = gd_eg(WM), NEG = WM / EG;             // epilogue: channel tiles per transpose group
     constexpr int OSTR = EG * 64 + 16, NEK = EG * 2, CPP = EG * 4;
     constexpr int BOFF = DA * ABYTES, EOFF = BOFF + DB * BBYTES, BIAS_OFF = EOFF + NW * 32 * OSTR, DUMMY_OFF = BIAS_OFF + TM * 4;
-    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0;
+    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0, OUT4 = (EPI & 4) != 0;
+    static_assert(!OUT4 || (NWM == 1 && WM == 3 && gd_eg(WM) == 3 && !BF), "the fused narrow layer needs the wave's whole 96-channel tile in its LDS region");
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = w / NWM, wm = w - wp * NWM;
@@ -128,6 +136,11 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     for (int c = 0; c < lead && c < total; ++c) issue_next();
     float* bl = reinterpret_cast<float*>(smem + BIAS_OFF);
     if (tid < TM) bl[tid] = (a.bias && tid < a.M) ? a.bias[tid] : 0.f;
+    half8 w4f[6];                         // OUT4: the narrow layer's weights, rows l31, K = 96 in six K-steps: registers for the whole launch
+    if constexpr (OUT4) {
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) w4f[ks] = *reinterpret_cast<const half8*>(x.w4 + l31 * 96 + ks * 16 + (lane >> 5) * 8);
+    }
     __syncthreads();
 
     // fragment addresses: row l31 of a 32-row block, K half kh of K-step s -> piece (2s + kh) ^ ((l31 >> 2) & 3)
@@ -210,6 +223,29 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                         const int piece = me * 4 + 2 * gp + kh;
                         *reinterpret_cast<u32x4_t*>(reg + l31 * OSTR + piece * 16) = o;
                     }
+                if constexpr (OUT4) {
+                    // the narrow layer on the rounded tile just parked in LDS: D[m][pixel] = sum_k w4[m][k] * tile[pixel][k], k ascending on one
+                    // accumulator (the order of the separate launch: bit-identical), + bias, fp32 NCHW stores coalesced along the pixels
+                    f32x16 a4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a4[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) {
+                        const half8 bq = *reinterpret_cast<const half8*>(reg + l31 * OSTR + (ks * 16 + kh * 8) * 2);
+                        a4 = gd_mma<false>(w4f[ks], bq, a4);
+                    }
+                    const int pix = pix_p + l31;
+                    const int n4 = pix / x.HW, rem = pix - n4 * x.HW;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = 8 * (r >> 2) + 4 * kh + (r & 3);
+                        if (m >= x.M4) continue;
+                        float v = a4[r];
+                        if (x.b4) v += x.b4[m];
+                        if (x.act4) v = lrelu(v);
+                        x.out32[((long long)n4 * x.M4 + m) * x.HW + rem] = v;
+                    }
+                }
                 // LDS -> HBM: 32 pixels x CPP 16-byte pieces, pixel-contiguous runs of EG * 64 bytes
                 u32x4_t mb[NEK];
                 int goff[NEK], loff[NEK];
@@ -288,7 +324,7 @@ int gemm_dma_lds_bytes(const ssdn_conv_args* a) {
 }
 
 template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
-static int gd_launch(const ssdn_conv_args* a, hipStream_t s) {
+static int gd_launch(const ssdn_conv_args* a, hipStream_t s, const ssdn_conv_args* a4 = nullptr) {
     constexpr int TP = NWP * WP * 32, TM = NWM * WM * 32;
     constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + NWP * NWM * 32 * (gd_eg(WM) * 64 + 16) + TM * 4 + 1024;
     static_assert(TP == 256 && NWP * NWM == 8, "gemm_dma_lds_bytes assumes 256-pixel tiles and 8 waves");
@@ -304,6 +340,8 @@ static int gd_launch(const ssdn_conv_args* a, hipStream_t s) {
     while ((1 << x.lp) < a->H) ++x.lp;
     const double px = (double)a->N * a->H * a->W;
     x.ntiles = (int)(px / TP);
+    x.w4 = nullptr; x.b4 = nullptr; x.out32 = nullptr; x.M4 = 0; x.act4 = 0; x.HW = a->H * a->W;
+    if (a4) { x.w4 = (const h16*)a4->w; x.b4 = a4->bias; x.out32 = a4->dst32; x.M4 = a4->M; x.act4 = a4->act; }
     const int kreal = a->kreal > 0 ? a->kreal : a->Ktot;
     prof_begin(SSDN_PROF_GEMM, s);
     int cus = ssdn_device_cus();
@@ -324,4 +362,17 @@ int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s) {
     }
     if (!a->bf16) return gd_launch<1, 3, 8, 1, false, 0>(a, s);
     return epi ? gd_launch<1, 3, 8, 1, true, 1>(a, s) : gd_launch<1, 3, 8, 1, true, 0>(a, s);
+}
+
+// the narrow 1x1 layer `b` (net_out: <= 32 output channels, fp32 NCHW) directly behind the 96-channel 1x1 layer `a` can ride in a's launch
+bool gemm_dma_fuses_next(const ssdn_conv_args* a, const ssdn_conv_args* b) {
+    if (!gemm_dma_eligible(a) || a->bf16 || a->mask.p || a->unrot.p || a->Mpad != 96 || !a->dst.p) return false;
+    if (b->bf16 || b->ntaps != 1 || b->dy[0] || b->dx[0] || b->up0 || b->c1 || b->c0 != 96 || b->Ktot != 96 || b->Mpad != 32 || b->M > 32) return false;
+    if (!b->dst32 || b->mask.p || b->add.p || b->pool.p || b->upsum.p || b->unrot.p || !b->w) return false;
+    if (b->src0.p != a->dst.p || b->src0.cs != a->dst.cs || b->src0.co != a->dst.co) return false;
+    return b->N == a->N && b->H == a->H && b->W == a->W;
+}
+int launch_gemm_dma_with_next(const ssdn_conv_args* a, const ssdn_conv_args* b, hipStream_t s) {
+    if (!gemm_dma_fuses_next(a, b)) return ssdn_set_error("gemm: the second layer cannot ride in this launch");
+    return gd_launch<1, 3, 8, 1, false, 4>(a, s, b);
 }
