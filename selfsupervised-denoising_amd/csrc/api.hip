@@ -289,7 +289,15 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
                 i += m - 1;
                 break;
             }
-            case SSDN_OP_GRAD_PACK: arm(i + 1); rc = launch_grad_pack((const ssdn_grad_pack_args*)p, s); break;
+            case SSDN_OP_GRAD_PACK: {    // ... directly followed by the narrow layer's data gradient that reads it: one launch (gradpack_dgrad.hip)
+                const bool next_conv = i + 1 < n && ops[i + 1].type == SSDN_OP_CONV && ops[i + 1].args && (one_lane ? 0 : ops[i + 1].lane) == lane;
+                if (next_conv && chain_merging_on() && conv_gradpack_fusable((const ssdn_grad_pack_args*)p, (const ssdn_conv_args*)ops[i + 1].args)) {
+                    arm(i + 2);
+                    rc = launch_gradpack_dgrad((const ssdn_grad_pack_args*)p, (const ssdn_conv_args*)ops[i + 1].args, s);
+                    ++i;
+                } else { arm(i + 1); rc = launch_grad_pack((const ssdn_grad_pack_args*)p, s); }
+                break;
+            }
             case SSDN_OP_HEAD_SSDN: rc = launch_head((const ssdn_head_args*)p, s); break;
             case SSDN_OP_HEAD_FINAL: rc = launch_head_final((const ssdn_head_final_args*)p, s); break;
             case SSDN_OP_SPATIAL_MEAN: rc = launch_spatial_mean((const ssdn_spatial_mean_args*)p, s); break;

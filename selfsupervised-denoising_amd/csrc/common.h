@@ -149,6 +149,10 @@ bool conv_thin_eligible(const ssdn_conv_args* a);
 bool conv_thin_fuses_pack(const ssdn_pack_input_args* pk, const ssdn_conv_args* a);   // (the conv must still pass launch_conv's own routing)
 int launch_conv_thin(const ssdn_conv_args* a, const ssdn_pack_input_args* pk, hipStream_t s);
 bool conv_pack_fusable(const ssdn_pack_input_args* pk, const ssdn_conv_args* a);      // conv_mfma.hip: launch_conv would route `a` to k_conv_thin
+// gradpack_dgrad.hip: SSDN_OP_GRAD_PACK + the data gradient of the narrow net_out layer behind it as one launch
+bool gradpack_dgrad_fusable(const ssdn_grad_pack_args* gp, const ssdn_conv_args* a);
+int launch_gradpack_dgrad(const ssdn_grad_pack_args* gp, const ssdn_conv_args* a, hipStream_t s);
+bool conv_gradpack_fusable(const ssdn_grad_pack_args* gp, const ssdn_conv_args* a);   // conv_mfma.hip: ... and launch_conv would run `a` as plain k_conv
 // gemm_dma.hip: 1x1 layers with 96 / 384 output channels as a one-pass LDS-DMA GEMM
 bool gemm_dma_eligible(const ssdn_conv_args* a);
 int gemm_dma_lds_bytes(const ssdn_conv_args* a);

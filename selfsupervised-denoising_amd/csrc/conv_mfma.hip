@@ -786,6 +786,9 @@ extern "C" int ssdn_conv_set_mode(int mode) {
 static bool conv_use_dma(const ssdn_conv_args* a) { return g_conv_mode > 0 && !a->pool.p && conv_dma_eligible(a, g_conv_mode == 2); }
 static bool conv_use_gemm(const ssdn_conv_args* a) { return g_conv_mode > 0 && gemm_dma_eligible(a); }
 static bool conv_use_thin(const ssdn_conv_args* a) { return g_conv_mode > 0 && conv_thin_eligible(a); }
+bool conv_gradpack_fusable(const ssdn_grad_pack_args* gp, const ssdn_conv_args* a) {
+    return !conv_validate(a) && !conv_use_gemm(a) && !conv_use_thin(a) && !conv_use_dma(a) && gradpack_dgrad_fusable(gp, a);
+}
 bool conv_pair_fusable(const ssdn_conv_args* a, const ssdn_conv_args* b) {
     return !conv_validate(a) && !conv_validate(b) && conv_use_gemm(a) && gemm_dma_fuses_next(a, b);
 }

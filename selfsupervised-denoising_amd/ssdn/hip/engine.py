@@ -163,6 +163,13 @@ class DeviceNet:
         out, names, pending = [], [], {k: [] for k in range(len(buckets))}
         pending_small = {k: [] for k in range(len(buckets))}
         pending_main = {k: [] for k in range(len(buckets))}
+        # SSDN_OP_GRAD_PACK and the narrow net_out layer's data gradient behind it are ONE launch when adjacent (csrc/gradpack_dgrad.hip): the
+        # weight-gradient record the planner puts between them waits behind the pair (it needs the pair's output anyway)
+        hold_to, held = -1, []
+        if plan.bwd[0].type == "grad_pack":
+            j = next((k for k in range(1, len(plan.bwd)) if plan.bwd[k].type not in ("wgrad", "wreduce")), -1)
+            if j > 1 and plan.bwd[j].type == "conv" and plan.bwd[j].a["role"] == "dgrad" and len(plan.bwd[j].a["taps"]) == 1 and plan.bwd[j].a["Ktot"] == 16:
+                hold_to = j
         for i, (op, rec) in enumerate(zip(plan.bwd, recs)):
             if op.type == "wreduce":
                 pending[bucket_of[op.a["layer"]]].append((rec, op.a["layer"]))
@@ -170,9 +177,15 @@ class DeviceNet:
                 pending_main[bucket_of[op.a["layer"]]].append((rec[0], rec[1], 0))
             elif grouped(op):
                 pending_small[bucket_of[op.a["layer"]]].append(rec)
+            elif op.type == "wgrad" and i < hold_to:
+                held.append(rec)
             else:
                 out.append(rec)
                 names.append(None)
+                if i == hold_to:
+                    out += held
+                    names += [None] * len(held)
+                    held = []
             for k in sorted(set(flush_at) | set(last)):          # bucket by bucket: a bucket's merged launch, then its reductions
                 if flush_at.get(k) == i:
                     out += pending_small[k]
