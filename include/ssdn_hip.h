@@ -30,8 +30,12 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+/* the library is built with -fvisibility=hidden: the functions declared here are its whole dynamic symbol table */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
 
-#define SSDN_ABI_VERSION 7
+#define SSDN_ABI_VERSION 8
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -229,6 +233,11 @@ typedef struct ssdn_wgrad_args {
     int32_t kreal;         /* real (un-padded) input channels among the Ktot slots, or 0 (unknown).  1..3 real channels under a
                               3x3 window (the network's first layer and the image half of decode_block_1.0) are served by the
                               im2col kernel k_wgrad_thin: 9 * kreal + 1 <= 32 GEMM columns instead of 9 x 32 */
+    int32_t mega;          /* > 0: the op is planned as part of ONE chip-wide launch of `mega` workgroups (one per CU) together with
+                              the SSDN_OP_WGRAD ops next to it in the list that carry the same value: every block of every op's
+                              grid becomes an item, items are packed onto the workgroups longest first by `cost`; each item runs
+                              the code of its op's own launch (bit-identical slabs).  0: the op is launched on its own */
+    float cost;            /* planner's estimate of the time of ONE block of this op's grid, any unit (only the ratios matter) */
 } ssdn_wgrad_args;
 
 /* ---- SSDN_OP_WREDUCE ------------------------------------------------------------------------
@@ -417,6 +426,11 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream);
 /* Bytes of dynamic LDS a conv op will request (host-side check of a tiling), or < 0 if the tiling is invalid. */
 int ssdn_conv_lds_bytes(const ssdn_conv_args* a);
 int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a);
+/* 1 if the op (mega > 0) can be an entry of the chip-wide weight-gradient launch, 0 if it needs a launch of its own */
+int ssdn_wgrad_mega_ok(const ssdn_wgrad_args* a);
+/* The kernel variant the library runs the op with: out9 = {thin, MT, CPW, NL, BOTH, PS, KS, RWX, RWD}; returns the id of its
+ * instance inside the chip-wide launch (>= 0), -1 if there is none, < -1 on invalid arguments.  (planner / test aid) */
+int ssdn_wgrad_variant(const ssdn_wgrad_args* a, int32_t* out9);
 
 /* sizeof() of the args struct for an op type (0: ssdn_op itself); lets a binding verify its struct mirrors */
 int ssdn_struct_size(int op_type);
@@ -484,6 +498,9 @@ void* ssdn_debug_get_trace(void);
 int ssdn_probe_mfma(const void* a_frag, const void* b_frag, float* d_out, void* stream);
 int ssdn_probe_tr16(const void* lds_image, int image_bytes, const int32_t* lane_addr, void* out, void* stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

@@ -216,7 +216,7 @@ class Interp:
         self.store(dst, cpad, out)
 
     def op_wgrad(self, layer, dz, src0, src1, c0, c1, up0, N, H, W, taps, coff, M, Mpad, Ktot, Kpad, nslabs, ltw, lth, ltn,
-                 slab=None, bslab=None, csplit=0, mblocks=1, kreal=0):
+                 slab=None, bslab=None, csplit=0, mblocks=1, kreal=0, mega=0, cost=0.0, **_planner_private):
         x = _r16(self._gather(src0, src1, c0, c1, up0, N, H, W), self.fp16, "bf16")   # staged as bf16 on the device
         self.slabs, self.bslabs = [], []
         for mb in range(mblocks):        # a merged launch covers mblocks blocks of M output channels of the dz view

@@ -140,6 +140,7 @@ int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* f
 int ssdn_conv_lds_bytes(const ssdn_conv_args* a) { return conv_lds_bytes(a); }
 int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a) { return wgrad_lds_bytes(a); }
 int ssdn_wgrad_mergeable(const ssdn_wgrad_args* a) { return a && wgrad_mergeable(a) ? 1 : 0; }
+int ssdn_wgrad_mega_ok(const ssdn_wgrad_args* a) { return wgrad_mega_ok(a); }
 int ssdn_conv_fuses_pool(const ssdn_conv_args* a) { return a && conv_fuses_pool(a) ? 1 : 0; }
 int ssdn_conv_fuses_upsum(const ssdn_conv_args* a) { return a && conv_fuses_upsum(a) ? 1 : 0; }
 int ssdn_conv_fuses_unrot(const ssdn_conv_args* a) { return a && conv_fuses_unrot(a) ? 1 : 0; }
@@ -259,6 +260,16 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             case SSDN_OP_UNROT_BWD: arm(i + 1); rc = launch_unrot_bwd((const ssdn_unrot_args*)p, s); break;
             case SSDN_OP_WGRAD: {   // a run of consecutive small-layer weight-gradient GEMMs on the same lane is one launch
                 static const bool no_merge = ssdn_tuning_env("SSDN_NO_WGRAD_MERGE") != nullptr;      // A/B aid, read once
+                // ... and a run of ops planned for one chip-wide launch (ssdn_wgrad_args.mega) is ONE launch, one workgroup per CU
+                {
+                    const ssdn_wgrad_args* mg[WGRAD_MEGA_MAX];
+                    int mm = 0;
+                    while (!no_merge && mm < WGRAD_MEGA_MAX && i + mm < n && ops[i + mm].type == SSDN_OP_WGRAD && ops[i + mm].args &&
+                           (one_lane ? 0 : ops[i + mm].lane) == lane && wgrad_mega_ok((const ssdn_wgrad_args*)ops[i + mm].args) &&
+                           ((const ssdn_wgrad_args*)ops[i + mm].args)->mega == ((const ssdn_wgrad_args*)p)->mega)
+                        mg[mm] = (const ssdn_wgrad_args*)ops[i + mm].args, ++mm;
+                    if (mm > 1) { arm(i + mm); rc = launch_wgrad_mega(mg, mm, s); i += mm - 1; break; }
+                }
                 const ssdn_wgrad_args* items[WGRAD_MULTI_MAX];
                 int m = 0;
                 while (!no_merge && m < WGRAD_MULTI_MAX && i + m < n && ops[i + m].type == SSDN_OP_WGRAD && ops[i + m].args &&

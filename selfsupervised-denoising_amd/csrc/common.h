@@ -106,6 +106,9 @@ int launch_conv(const ssdn_conv_args* a, hipStream_t s);
 int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s);
 bool wgrad_mergeable(const ssdn_wgrad_args* a);                 // small layer with a k_wgrad_multi instance
 int launch_wgrad_multi(const ssdn_wgrad_args* const* items, int n, hipStream_t s);
+#define WGRAD_MEGA_MAX 64
+int wgrad_mega_ok(const ssdn_wgrad_args* a);                    // mega > 0 and the op has a k_wgrad_mega instance
+int launch_wgrad_mega(const ssdn_wgrad_args* const* ops, int n, hipStream_t s);   // a whole bucket's weight gradients, one workgroup per CU
 int launch_pack_input(const ssdn_pack_input_args* a, hipStream_t s);
 int launch_pool_fwd(const ssdn_pool_args* a, hipStream_t s);
 int launch_pool_bwd(const ssdn_pool_args* a, hipStream_t s);

@@ -145,8 +145,9 @@ class DevicePatchStream:
         clean = torch.empty((B, Cn, H, W), **f32)
         inp = None
         if self._denoiser is not None and getattr(self._denoiser, "training", False):
-            buf = self._denoiser.input_buffer(B, H, W)
-            if tuple(buf.shape) == (B, Cn, H, W) and buf.device == dev:
+            box_ = n2v_ups._box_size() if n2v else 0
+            buf = self._denoiser.input_buffer(B, H, W, ncoords=((W // box_) * (H // box_) if n2v else 64))
+            if buf is not None and tuple(buf.shape) == (B, Cn, H, W) and buf.device == dev:
                 inp = buf
         if inp is None:
             inp = torch.empty((B, Cn, H, W), **f32)
@@ -176,6 +177,7 @@ class DevicePatchStream:
             k = ("coeff", fixed)
             if k not in st:
                 st[k] = torch.full((B, 1, 1, 1), float(fixed), **f32)
+                st[k]._ssdn_const = True        # never rewritten: Denoiser uploads this very object once (denoiser.py, KNOWN sigma)
             return st[k]
         metadata: Dict = {}
         if n2v:

@@ -192,11 +192,14 @@ class Denoiser(nn.Module):
         them across calls.  (`train_step` uses the engine's buffers directly.)"""
         return self._run(data, clone=True)
 
-    def input_buffer(self, B: int, H: int, W: int) -> Tensor:
+    def input_buffer(self, B: int, H: int, W: int, ncoords: int = 64) -> Optional[Tensor]:
         """The fp32 [B, C, H, W] input buffer of the TRAINING engine for this shape.  A producer that writes the noisy minibatch
         straight into it (ssdn.datasets.DevicePatchStream does, when attached) and passes that very tensor as the pipeline
-        input saves `run_pipeline` its device-to-device copy; the buffer is overwritten by the next minibatch."""
-        return self._engine(B, H, W, True).inp
+        input saves `run_pipeline` its device-to-device copy; the buffer is overwritten by the next minibatch.
+        Never BUILDS an engine (a plan owns ~1 GB) and never touches the LRU order or the weight shadows: None until the first
+        training step of this shape has created it (the producer then uses a buffer of its own, once)."""
+        slot = self._engines.get((B, H, W, True, ncoords))
+        return slot[0].inp if slot is not None else None
 
     def _run(self, data: List, clone: bool, bridge: bool = True) -> Dict:
         if self._pipeline not in (Pipeline.MSE, Pipeline.SSDN, Pipeline.MASK_MSE):
@@ -219,11 +222,13 @@ class Denoiser(nn.Module):
         if self._pipeline == Pipeline.SSDN:
             if self.cfg[ConfigValue.NOISE_VALUE] == NoiseValue.KNOWN:
                 npv = meta[MD.INPUT_NOISE_VALUES]
-                # the same (device) parameter tensor as in the previous step, unmodified: nothing to upload again
-                tag = (npv.data_ptr(), npv._version, tuple(npv.shape)) if npv.device == eng.noise_param.device else None
-                if tag is None or getattr(eng, "_np_tag", None) != tag:
+                # A producer may mark a parameter tensor it never rewrites (DevicePatchStream's cached constant of a fixed-sigma style:
+                # `_ssdn_const`); that very OBJECT (held by reference, so its address cannot be handed out again) is uploaded once.
+                # Everything else -- e.g. the per-minibatch tensor of a ranged style, filled through a raw pointer, whose
+                # (address, _version) can repeat with different contents -- is copied every step (B floats, device to device).
+                if not (getattr(npv, "_ssdn_const", False) and npv is getattr(eng, "_np_src", None)):
                     eng.noise_param.copy_(npv.reshape(B).to(torch.float32), non_blocking=True)
-                    eng._np_tag = tag
+                    eng._np_src = npv if getattr(npv, "_ssdn_const", False) else None
         else:
             have_loss = ref is not None and (self._pipeline == Pipeline.MSE or coords is not None)
             if have_loss:

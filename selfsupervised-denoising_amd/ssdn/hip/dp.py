@@ -31,11 +31,13 @@ def env_world() -> Tuple[int, int, int]:
 
 def init_from_env(backend: Optional[str] = None, device_index: Optional[int] = None) -> Tuple[int, int, int]:
     """Join the job described by RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT (torchrun sets them) and select
-    this rank's GPU (LOCAL_RANK unless `device_index` says otherwise) before anything is allocated."""
+    this rank's GPU (LOCAL_RANK unless `device_index` says otherwise) before anything is allocated.  Process-wide side
+    effects happen only when there is a job to join (WORLD_SIZE > 1) or a device is named explicitly: constructing a trainer
+    in a single-process program (evaluation included) leaves the caller's current device alone."""
     rank, world, local = env_world()
     have_gpu = torch.cuda.is_available()
     dev = local if device_index is None else device_index
-    if have_gpu:
+    if have_gpu and (world > 1 or device_index is not None):
         torch.cuda.set_device(dev)
     if world > 1 and not dist.is_initialized():
         if backend is None:
@@ -85,6 +87,10 @@ class GradExchange:
     def __init__(self, world: int, ranges: Sequence[Tuple[int, int]], device: Optional[torch.device] = None,
                  force_events: bool = False):
         self.world, self.ranges = world, [(int(lo), int(hi)) for lo, hi in ranges]
+        # force_events with an initialised process group: the collectives are issued even for world 1 (an identity all-reduce
+        # through RCCL: the communication stream, the event waits and the asynchronous work handles all run -- the -m gpu test
+        # of the exchange on a 1-GPU box)
+        self.force = bool(force_events)
         self.pending: list = []
         self.device = torch.device(device) if device is not None else None
         self.cuda = self.device is not None and self.device.type == "cuda"
@@ -112,7 +118,7 @@ class GradExchange:
             self.events[k].record(torch.cuda.current_stream(self.device))
 
     def launch(self, flat_grad: torch.Tensor):
-        if self.world <= 1:
+        if self.world <= 1 and not (self.force and dist.is_available() and dist.is_initialized()):
             return
         for k, (lo, hi) in enumerate(self.ranges):
             if hi <= lo:

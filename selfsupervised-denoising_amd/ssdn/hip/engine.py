@@ -108,7 +108,63 @@ class DeviceNet:
         return ol
 
     @staticmethod
+    def _order_mega(plan, recs):
+        """Backward list of a plan whose weight gradients run as chip-wide launches (graph.WGRAD_MEGA): the main-lane ops in the
+        planner's order; the SSDN_OP_WGRAD records of a launch group consecutive (the executor runs such a run as ONE k_wgrad_mega
+        launch), placed behind the main-lane op that produces the group's last gradient operand, directly followed by the group's
+        slab reductions (a run of reductions is two launches).  A group that would fall inside a run of chainable main-lane ops
+        (k_conv_chain) waits behind the run.  Returns (records, layer name of each record if it is a reduction else None)."""
+        side = lambda op: op.type in ("wgrad", "wreduce")   # noqa: E731
+        gof = lambda op: plan.wgrad_group_of(op.a["layer"])  # noqa: E731
+        flush = {}
+        for i, op in enumerate(plan.bwd):
+            if op.type == "wgrad":
+                flush[gof(op)] = i
+        def chainable(op):
+            if op.type == "conv":
+                px = op.a["H"] * op.a["W"]
+                thin = px == 256 and op.a["Mpad"] <= 64 and op.a["Ktot"] <= 48 and op.a.get("upsum") is None
+                return op.a["role"] == "dgrad" and len(op.a["taps"]) == 9 and (px <= 64 or thin)
+            return op.type == "pool_bwd" and (op.a["H"] // 2) * (op.a["W"] // 2) <= 256
+        windows, cur = [], None
+        for i, op in enumerate(plan.bwd):
+            if chainable(op):
+                cur = [i, i] if cur is None else [cur[0], i]
+            elif not side(op) and cur is not None:
+                windows.append(cur)
+                cur = None
+        if cur is not None:
+            windows.append(cur)
+        for first, end in windows:
+            for g in flush:
+                if first <= flush[g] < end:
+                    flush[g] = end
+        out, names = [], []
+        for i, (op, rec) in enumerate(zip(plan.bwd, recs)):
+            if not side(op):
+                out.append(rec)
+                names.append(None)
+            for g in sorted(flush):
+                if flush[g] != i:
+                    continue
+                for op2, rec2 in zip(plan.bwd, recs):
+                    if op2.type == "wgrad" and gof(op2) == g:
+                        out.append((rec2[0], rec2[1], MEGA_LANE))
+                        names.append(None)
+                for op2, rec2 in zip(plan.bwd, recs):
+                    if op2.type == "wreduce" and gof(op2) == g:
+                        out.append((rec2[0], rec2[1], MEGA_LANE))
+                        names.append(op2.a["layer"])
+        return out, names
+
+    @staticmethod
     def _group_reductions(plan, recs):
+        if getattr(plan, "_mega_ops", None):
+            return DeviceNet._order_mega(plan, recs)
+        return DeviceNet._group_reductions_lanes(plan, recs)
+
+    @staticmethod
+    def _group_reductions_lanes(plan, recs):
         """Move every slab reduction to the end of its gradient bucket (ssdn.hip.dp.bucket_layers: head+dec1 | dec2..dec5 |
         encoder): the executor merges a run of consecutive SSDN_OP_WREDUCE ops into two launches, instead of two launches per
         layer (51 latency-bound launches, 0.52 ms per step in situ).  Legal: every weight-gradient launch owns its slab and
@@ -291,6 +347,7 @@ class DeviceNet:
             s.csplit = a.get("csplit", 0)
             s.mblocks = a.get("mblocks", 1)
             s.kreal = a.get("kreal", 0)
+            s.mega, s.cost = a.get("mega", 0), a.get("cost", 0.0)
             if L.load().ssdn_wgrad_lds_bytes(C.byref(s)) < 0:
                 raise L.SsdnHipError("wgrad %s: %s" % (a["layer"], L.load().ssdn_last_error().decode()))
             return op.type, s
@@ -332,6 +389,10 @@ DEFER_TAIL = True
 # bucket's merged weight-gradient launch behind the whole run makes ONE chain of 12 ops, but that launch then waits for the end of the
 # chain; leaving it where the bucket's last gradient appears makes two chains (3 + 9 ops) and starts it ~100 us earlier.
 CHAIN_POSTPONES = (2,)          # measured (tools/ab_lanes.py, same process): all buckets 1.975 ms per step, the encoder bucket only 1.959, none 1.965
+
+# Lane of the chip-wide weight-gradient launches and their slab reductions (graph.WGRAD_MEGA).  A workgroup of those launches owns its
+# CU, one per CU: next to them nothing else runs, so they sit on the main lane (0), behind the data gradients whose results they read.
+MEGA_LANE = 0
 
 STYLE = {"gauss": 0, "poisson": 1}
 MODE = {"known": 0, "const": 1, "var": 2}

@@ -23,6 +23,23 @@ CONV_LDS_PREFERRED = 80 * 1024
 WGRAD_SMALL_PX = 32768        # layers with at most this many pixels (16x16 and below at BASELINE sizes) share merged launches ...
 SMALL_WGRAD_G, SMALL_WGRAD_CUS = 2, 64      # ... planned as two column groups on <= 64 / 2 pixel partitions
 MID_WGRAD_PX, MID_WGRAD_G = 131072, 2       # the 32x32 stage: two column groups on half the partitions
+WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient grids are planned for (see _wgrad)
+# Round 4: the weight gradients of a whole group of layers as ONE chip-wide launch (k_wgrad_mega, csrc/wgrad_mfma.hip): one
+# workgroup per CU, every op's grid sized by the cost model below so that all workgroups finish together.
+#   "all": one launch behind the last data gradient; "buckets": one per gradient bucket (ssdn.hip.dp.bucket_layers);
+#   None: round 3's per-layer launches on the side lane
+WGRAD_MEGA = "all"
+# cost model of one weight-gradient block, in cycles (calibrated on BASELINE config 2 with tools/wgrad_calib.py):
+#   K-step of 16 pixels = base + per_mfma * MT * CPW;  a block = tiles * ksteps * K-step + fixed + slab bytes / slab_rate
+MEGA_COST = {
+    "static": (300.0, 24.0),      # compile-time staging schedules (3x3 layers, 16x8-pixel tiles)
+    "generic": (1000.0, 33.0),    # run-time staging (small layers, odd tiles)
+    "head": (800.0, 0.0),         # 1x1 layers over four 96-channel input blocks (an input AND a dZ row per K-step)
+    "head_mb": (800.0, 0.0),      # ... with the 4 output blocks of a pixel partition side by side (input shared through L2)
+    "thin": (1900.0, 450.0),      # k_wgrad_thin: per 256-pixel tile: base + per 32 output channels
+    "fixed": 6000.0,              # prologue (first tile fetched synchronously) + item switch
+    "slab_rate": 10.0,            # bytes per cycle a workgroup writes its slab with
+}
 TAPS_BLIND = [(ky - 2, kx - 1) for ky in range(3) for kx in range(3)]   # ShiftConv2d: in[y+ky-2, x+kx-1]
 TAPS_PLAIN = [(ky - 1, kx - 1) for ky in range(3) for kx in range(3)]
 TAPS_1x1 = [(0, 0)]
@@ -347,6 +364,25 @@ class NetPlan:
         # tile it can prefetch.)
         slab_bytes = ntaps * Mpad * Kpad * 4
         ctiles = ntaps * Kpad // 32 + 1
+        if WGRAD_MEGA and self.cus >= 64:
+            # planned later, together with the other ops of its launch (_plan_mega): grid, tile, slabs, cost
+            self.nwgrad = getattr(self, "nwgrad", 0) + 1
+            op = Op("wgrad", dict(layer=layer.name, dz=dz, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
+                                  taps=list(taps), coff=coff, M=Mz, Mpad=Mpad, Ktot=Ktot, Kpad=Kpad, nslabs=0, ltw=0, lth=0, ltn=0,
+                                  csplit=0, mblocks=mblocks, slab=None, bslab=None, kreal=int(cin_real) if cblocks is None else 0,
+                                  mega=0, cost=0.0, _id=self.nwgrad, _cblocks=cblocks is not None))
+            self.bwd.append(op)
+            reds = []
+            for mb in range(mblocks):
+                mo = m_off + mb * Mz
+                M_real = min(Mz, layer.M - mo)
+                r = Op("wreduce", dict(layer=layer.name, nslabs=0, ntaps=ntaps, M=M_real, Mpad=Mpad, Kpad=Kpad, cin=cin_real,
+                                       cin_full=layer.cin, m_off=mo, c_off=c_off, with_bias=with_bias, tapblock=int(cblocks is not None),
+                                       mblock=mb, slab=None, bslab=None))
+                self.bwd.append(r)
+                reds.append(r)
+            self._mega_ops = getattr(self, "_mega_ops", []) + [(op, reds)]
+            return
 
         def candidate(G):
             cpw = -(-ctiles // (4 * G))
@@ -355,7 +391,7 @@ class NetPlan:
             # persistent grids for 3/4 of the CUs keeps both lanes running side by side (measured on BASELINE config 2, two
             # boxes: 256 -> 2.35 ms, 208 -> 2.35, 192 -> 2.27 / 2.30, 160 -> 2.29, 128 -> 2.29 ms per step) and trims the slab
             # traffic by a quarter.
-            wcus = self.cus if self.cus < 64 else (3 * self.cus // 4) & ~7
+            wcus = self.cus if self.cus < 64 else (WGRAD_CU_FRAC[0] * self.cus // WGRAD_CU_FRAC[1]) & ~7
             cus_eff = max(1, wcus // G)
             if small and small_g > 0:
                 cus_eff = max(1, min(self.cus, small_cus) // G)
@@ -588,3 +624,130 @@ class NetPlan:
         g_e0 = self.grad("g_e0", N, H, W, 48)
         dgrad("encode_block_1.2", g_e1, 48, N, H, W, rt3, 48, View(g_e0), mask=View(e0))
         self._wgrad(L["encode_block_1.0"], View(g_e0), 48, None, 0, 0, View(x16), 16, C, N, H, W, t3)
+        if getattr(self, "_mega_ops", None):
+            self._plan_mega()
+
+    # ---- chip-wide weight-gradient launches ------------------------------------------------------------------
+    def wgrad_group_of(self, layer_name: str) -> int:
+        """index of the chip-wide launch the weight gradients of `layer_name` belong to (WGRAD_MEGA)"""
+        if WGRAD_MEGA != "buckets":
+            return 0
+        off = {l.name: l.w_off for l in self.layers}
+        a, b = off["decode_block_1.0"], off["decode_block_5.0"]        # (== ssdn.hip.dp.bucket_layers)
+        w = off[layer_name]
+        return 0 if w >= a else (1 if w >= b else 2)
+
+    @staticmethod
+    def _thin_ok(a) -> bool:
+        """csrc/wgrad_mfma.hip::wgrad_thin_ok"""
+        if not (1 <= a["kreal"] <= 3) or len(a["taps"]) != 9 or a["mblocks"] > 1:
+            return False
+        if a["H"] % 16 or a["W"] % 16 or a["M"] % 8 or a["Mpad"] > 96 or a["Kpad"] < a["kreal"]:
+            return False
+        if a["c0"] > 0 and (a["up0"] or a["c1"] > 0):
+            return False
+        if a["c0"] == 0 and a["c1"] <= 0:
+            return False
+        if any(c != 0 for c in a["coff"]):
+            return False
+        dys = [t[0] for t in a["taps"]]
+        dxs = [t[1] for t in a["taps"]]
+        return max(dys) - min(dys) == 2 and max(dxs) - min(dxs) == 2
+
+    def _mega_candidates(self, a):
+        """(tile, ntiles, cycles per tile, fixed cycles per block) of a weight-gradient op planned as ONE column group."""
+        C_ = MEGA_COST
+        N, H, W = a["N"], a["H"], a["W"]
+        ntaps, Mpad, Kpad = len(a["taps"]), a["Mpad"], a["Kpad"]
+        MT = Mpad // 32
+        slab_bytes = ntaps * Mpad * Kpad * 4
+        if self._thin_ok(a):
+            ntiles = N * (H // 16) * (W // 16)
+            fixed = C_["fixed"] + 9 * Mpad * 32 * 4 / C_["slab_rate"]
+            return (4, 4, 0), ntiles, C_["thin"][0] + C_["thin"][1] * MT, fixed
+        ctiles = ntaps * Kpad // 32 + 1
+        cpw = -(-ctiles // 4)
+        try:
+            tile, ntiles = choose_wgrad_tile(N, H, W, a["taps"], max(Kpad, a["Ktot"]), Mpad, a["Ktot"], a["M"], 1)
+        except ValueError:
+            # no tile the kernel could prefetch while another is on the matrix cores: one tile per workgroup (`min_ns`)
+            tile, ntiles = choose_wgrad_tile(N, H, W, a["taps"], max(Kpad, a["Ktot"]), Mpad, a["Ktot"], a["M"], self.cus)
+            a["_min_ns"] = ntiles
+        ltw, lth, ltn = tile
+        ksteps = (1 << sum(tile)) // 16
+        HW_ = (1 << ltw) + (max(t[1] for t in a["taps"]) - min(t[1] for t in a["taps"]))
+        ix = -(-(HW_ * (a["Ktot"] // 8)) // 64)
+        both = ix > 4
+        static = (not both) and ltn == 0 and ltw >= 3 and ksteps == 8 and MT >= 2 and cpw >= 2 and _wg_stride(max(Kpad, a["Ktot"]) * 2) == 192
+        if a["_cblocks"] and both:
+            kind = "head_mb" if a["mblocks"] > 1 else "head"
+        else:
+            kind = "static" if static else "generic"
+        # the run-time-staged variants with 21 accumulators per wave are not part of the chip-wide launch (register budget): such an
+        # op runs as two column groups (every tile is staged by two blocks; these are the layers with few pixels)
+        G = 2 if (kind == "generic" and MT * cpw > 16) else 1
+        a["csplit"] = G if G > 1 else 0
+        cpw = -(-ctiles // (4 * G))
+        base, per = C_[kind]
+        fixed = C_["fixed"] + slab_bytes / C_["slab_rate"] / G
+        return tile, ntiles, ksteps * (base + per * MT * cpw), fixed
+
+    def _plan_mega(self):
+        """Size the grid of every weight-gradient op so that the workgroups of its chip-wide launch (one per CU) finish together,
+        allocate the slabs, and give every op its cost per block (the library packs the blocks onto the workgroups by it)."""
+        W = self.cus
+        groups: Dict[int, list] = {}
+        for op, reds in self._mega_ops:
+            groups.setdefault(self.wgrad_group_of(op.a["layer"]), []).append((op, reds))
+        self.mega_makespan = {}
+        for gi, members in sorted(groups.items()):
+            cand = []
+            for op, reds in members:
+                tile, ntiles, c_tile, fixed = self._mega_candidates(op.a)
+                mb = max(1, op.a["mblocks"])
+                G = max(1, op.a.get("csplit", 0))
+                cand.append(dict(op=op, reds=reds, tile=tile, ntiles=ntiles, c_tile=c_tile, fixed=fixed, mb=mb * G, nmb=mb))
+            # t = the time a block should take: an op with `work` cycles gets ceil(work / (t - fixed)) blocks.  The launch has one
+            # block per (op, partition), dispatched longest first onto the CUs as they free up (a block owns its CU): the plan is the
+            # t whose simulated dispatch ends first.
+            def blocks_for(t):
+                res = []
+                for c in cand:
+                    ns = -(-int(c["ntiles"] * c["c_tile"]) // max(1, int(t - c["fixed"])))
+                    ns = max(1, min(c["ntiles"], ns, max(1, W // c["mb"])))
+                    ns = max(ns, c["op"].a.get("_min_ns", 1))
+                    res.append((ns, -(-c["ntiles"] // ns) * c["c_tile"] + c["fixed"]))
+                return res
+
+            def makespan(blocks):
+                import heapq
+                items = sorted((cost for (ns, cost), c in zip(blocks, cand) for _ in range(ns * c["mb"])), reverse=True)
+                free = [0.0] * W
+                heapq.heapify(free)
+                end = 0.0
+                for it in items:
+                    t0 = heapq.heappop(free)
+                    heapq.heappush(free, t0 + it)
+                    end = max(end, t0 + it)
+                return end, sum(items) / W
+            lower = sum(c["ntiles"] * c["c_tile"] * c["mb"] for c in cand) / float(W)
+            best = None
+            for k in range(120):
+                t = lower * (1.0 + 0.01 * k) + max(c["fixed"] for c in cand)
+                bl = blocks_for(t)
+                ms = makespan(bl)
+                if best is None or ms[0] < best[0][0]:
+                    best = (ms, bl)
+            self.mega_makespan[gi] = best[0]
+            for c, (ns, cost) in zip(cand, best[1]):
+                c["ns"], c["cost"] = ns, cost
+            for c in cand:
+                a = c["op"].a
+                ns, mb = c["ns"], c["nmb"]
+                a["nslabs"], (a["ltw"], a["lth"], a["ltn"]) = ns, c["tile"]
+                a["mega"], a["cost"] = W, float(c["cost"])
+                ntaps = len(a["taps"])
+                a["slab"] = self.T("slab%d" % a["_id"], "f32", (mb * ns * ntaps * a["Mpad"] * a["Kpad"],))
+                a["bslab"] = self.T("bslab%d" % a["_id"], "f32", (mb * ns * a["Mpad"],))
+                for r in c["reds"]:
+                    r.a["nslabs"], r.a["slab"], r.a["bslab"] = ns, a["slab"], a["bslab"]

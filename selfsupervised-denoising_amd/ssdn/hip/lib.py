@@ -58,7 +58,7 @@ class WgradArgs(C.Structure):
     _fields_ = [("dz", View), ("src0", View), ("src1", View), ("c0", i32), ("c1", i32), ("up0", i32), ("N", i32),
                 ("H", i32), ("W", i32), ("ntaps", i32), ("dy", i32 * MAX_TAPS), ("dx", i32 * MAX_TAPS), ("coff", i32 * MAX_TAPS),
                 ("M", i32), ("Mpad", i32), ("Ktot", i32), ("Kpad", i32), ("slab", vp), ("bslab", vp), ("nslabs", i32), ("ltw", i32),
-                ("lth", i32), ("ltn", i32), ("csplit", i32), ("mblocks", i32), ("kreal", i32)]
+                ("lth", i32), ("ltn", i32), ("csplit", i32), ("mblocks", i32), ("kreal", i32), ("mega", i32), ("cost", C.c_float)]
 
 
 class WreduceArgs(C.Structure):
@@ -126,13 +126,13 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
                  mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 7      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 8      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
            "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_chain_len",
-           "ssdn_conv_set_chain"]
+           "ssdn_conv_set_chain", "ssdn_wgrad_mega_ok", "ssdn_wgrad_variant"]
 PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6)
 
 _lib = None
@@ -184,6 +184,10 @@ def load() -> C.CDLL:
     lib.ssdn_conv_fuses_pool.restype = C.c_int
     lib.ssdn_wgrad_mergeable.argtypes = [C.c_void_p]
     lib.ssdn_wgrad_mergeable.restype = C.c_int
+    lib.ssdn_wgrad_mega_ok.argtypes = [C.c_void_p]
+    lib.ssdn_wgrad_mega_ok.restype = C.c_int
+    lib.ssdn_wgrad_variant.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.ssdn_wgrad_variant.restype = C.c_int
     lib.ssdn_struct_size.argtypes = [C.c_int]
     lib.ssdn_struct_size.restype = C.c_int
     if lib.ssdn_abi_version() != ABI_VERSION:

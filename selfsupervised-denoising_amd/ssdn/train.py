@@ -63,6 +63,7 @@ class _RankShard(torch.utils.data.Sampler):
 
     def __iter__(self):
         batch = []
+        self.counts.clear()          # (counts of an abandoned earlier pass -- prefetched, never trained on -- must not leak into this one)
         for idx in self.sampler:
             batch.append(idx)
             if len(batch) == self.global_batch:
@@ -113,7 +114,8 @@ class DenoiserTrainer:
         self._exchange = None
 
     def new_target(self):
-        device = "cuda:%d" % self.local_rank if torch.cuda.is_available() else None
+        # (a single-process program keeps the device its caller selected; a rank of a job uses its own GPU)
+        device = "cuda:%d" % (self.local_rank if self.world > 1 else torch.cuda.current_device()) if torch.cuda.is_available() else None
         self.denoiser = Denoiser(self.cfg, device=device)
         self.init_state()
 

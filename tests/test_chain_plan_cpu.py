@@ -43,7 +43,10 @@ def test_chained_runs_of_the_materialised_lists(cin, cout, bs, B, P, fwd_len, bw
             assert [n for _, n in fwd] == [fwd_len]
             first = plan.fwd[fwd[0][0]]
             assert first.type == "conv" and first.a["H"] * first.a["W"] == 256 and first.a["M"] == 48      # encode_block_3: the thin 16x16 layer
-            assert [n for _, n in bwd] == bwd_lens
+            # (chip-wide weight-gradient launches wait behind the run of chainable ops: ONE backward chain; with round 3's per-layer
+            #  launches the decoder bucket's merged launch stays inside it: two)
+            from ssdn.hip import graph as G
+            assert [n for _, n in bwd] == ([sum(bwd_lens)] if G.WGRAD_MEGA else bwd_lens)
         else:
             assert all(n <= 8 for _, n in fwd) and all(n <= 12 for _, n in bwd)
         # every chained op is a main-lane conv / max-pool backward on small images, and the runs do not overlap

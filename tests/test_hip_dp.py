@@ -153,3 +153,55 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
                            env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
         lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         assert p.returncode != 0 and len(lines) == 1 and "error" in json.loads(lines[0]), p.stdout[-2000:]
+
+
+def _rccl_world1(port, q):
+    """(own process: the process group must not outlive the test, and RCCL initialises once per process)"""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    import torch.distributed as dist
+    from ssdn.hip import dp
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        clean, noisy = _inputs(4, 64)
+        clean, noisy = clean.cuda(), noisy.cuda()
+        plain = _steps(_make(), noisy, clean, None, nsteps=3)
+        d = _make()
+        ex = d.gradient_exchange(1)
+        assert not ex.overlapped                       # world 1 without the switch: nothing to exchange
+        ex = dp.GradExchange(1, ex.ranges, d.device, force_events=True)
+        assert ex.overlapped and ex.comm_stream is not None
+        seen = []
+        orig = dist.all_reduce
+
+        def counting(t, *a, **kw):
+            seen.append((t.numel(), bool(kw.get("async_op")), torch.cuda.current_stream().cuda_stream))
+            return orig(t, *a, **kw)
+        dist.all_reduce = counting
+        try:
+            got = _steps(d, noisy, clean, ex, nsteps=3)
+        finally:
+            dist.all_reduce = orig
+        dist.destroy_process_group()
+        q.put(("ok", plain, got, seen, ex.comm_stream.cuda_stream, [hi - lo for lo, hi in ex.ranges if hi > lo]))
+    except Exception as e:      # noqa: BLE001
+        import traceback
+        q.put(("err", traceback.format_exc(), None, None, None, None))
+
+
+def test_rccl_exchange_world_one_is_bit_identical():
+    """the RCCL code path of the gradient exchange on the ONE GPU of the test box.  A world-1 "nccl" process
+    group; `GradExchange(force_events=True)` drives the event-carrying backward list, the communication stream and one asynchronous
+    `dist.all_reduce` per bucket through RCCL (an identity reduction); Adam waits for the work handles.  Three optimisation steps must
+    leave exactly the weights of the run without an exchange."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1, args=(_free_port(), q))
+    p.start()
+    tag, plain, got, seen, comm, sizes = q.get(timeout=600)
+    p.join(timeout=120)
+    assert tag == "ok", plain
+    assert np.array_equal(plain, got)
+    # one asynchronous collective per bucket and step, issued from the communication stream
+    assert len(seen) == 3 * len(sizes) and all(a for _, a, _ in seen) and all(s == comm for _, _, s in seen)
+    assert sorted(n for n, _, _ in seen[:len(sizes)]) == sorted(sizes)

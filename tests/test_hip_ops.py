@@ -405,14 +405,17 @@ def test_full_size_config2_properties():
     assert not bad, "\n".join(bad)
 
 
-def test_merged_weight_gradient_launch_is_bit_identical():
-    """A run of consecutive small-layer SSDN_OP_WGRAD ops executes as ONE launch (k_wgrad_multi, csrc/wgrad_mfma.hip); every
-    workgroup runs the code of its own layer's launch, so the slabs must equal those of one-op-at-a-time execution bit for bit."""
+@pytest.mark.parametrize("B,P,mode", [(2, 32, "all"), (32, 64, "all"), (2, 32, None), (4, 64, "buckets")])
+def test_merged_weight_gradient_launch_is_bit_identical(B, P, mode, monkeypatch):
+    """A run of consecutive SSDN_OP_WGRAD ops executes as ONE launch -- the chip-wide k_wgrad_mega (csrc/wgrad_mega.hip: one workgroup
+    per CU works through a list of blocks of several ops' grids) or, for round 3's per-layer plans, k_wgrad_multi for the small layers;
+    every block runs the code of its own op's launch, so the gradients must equal those of one-op-at-a-time execution bit for bit."""
     import ctypes as C
     from ssdn.hip import lib as L
+    from ssdn.hip import graph as G
     from ssdn.hip.engine import DeviceNet, OpList, current_stream
     from ssdn.hip.graph import NetPlan
-    B, P = 2, 32
+    monkeypatch.setattr(G, "WGRAD_MEGA", mode)
     dev = torch.device("cuda:0")
     plan = NetPlan("m/", 3, 9, True, B, P, P, cus=L.load().ssdn_device_cus())
     g = torch.Generator(device="cpu").manual_seed(11)
@@ -438,11 +441,18 @@ def test_merged_weight_gradient_launch_is_bit_identical():
 
     one_by_one = run([OpList([r]) for r in recs])           # a run of one op is never merged
     merged = run([OpList(recs)])
-    nmerge = sum(1 for r in recs if L.load().ssdn_wgrad_mergeable(C.byref(r[1])))
-    assert nmerge >= 8, "the fixture must exercise the merged launch (%d mergeable ops)" % nmerge
+    if mode:
+        nmerge = sum(1 for r in recs if L.load().ssdn_wgrad_mega_ok(C.byref(r[1])))
+        assert nmerge == len(recs), "every op of the BASELINE plan must have an instance in the chip-wide launch (%d of %d)" % (nmerge, len(recs))
+    else:
+        nmerge = sum(1 for r in recs if L.load().ssdn_wgrad_mergeable(C.byref(r[1])))
+        assert nmerge >= 8, "the fixture must exercise the merged launch (%d mergeable ops)" % nmerge
     n = plan.nparams
     assert torch.isfinite(one_by_one[:n]).all()
     assert torch.equal(one_by_one[:n], merged[:n])
+    # ... and against fp64 on the CPU for a layer with many pixels and one with few (the lowering itself: teacher-forced tests)
+    again = run([OpList(recs)])
+    assert torch.equal(merged[:n], again[:n]), "the merged launch must be reproducible bit for bit"
 
 
 def _longest_chain(lib, ol):
