@@ -369,6 +369,17 @@ def run_rank(args):
                                "launches": int(cnt.value), "sampling": "every %dth launch of the timed region" % PROF_STRIDE, "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 3),
                                "kernel_time_share": round(PROF_STRIDE * ms.value / 1e3 / dt, 4)}
             res["families"] = families
+            # the time-dominant family next to the flop-dominant one: the weight gradients of the whole network,
+            # ONE chip-wide launch per step (k_wgrad_mega), bracketed in the family leg after the timed region
+            wg = families.get("wgrad")
+            if wg and wg.get("tflops_algorithmic"):
+                res["roofline"]["second_kernel"] = {
+                    "kernel": "k_wgrad_mega: weight + bias gradients of all 20 layers as one launch, one block per (op, pixel partition), a block owns its CU",
+                    "bound": "mfma", "achieved": wg["tflops_algorithmic"], "peak": MFMA_FP16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(wg["tflops_algorithmic"] / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "avg_launch_us": wg["avg_launch_us"],
+                    "launches_per_step": wg["launches_per_step"],
+                    "kernel_time_share": round(wg["ms_per_step_bracketed_sum"] / (1e3 * dt / args.steps), 4),
+                    "sampling": "every 3rd launch of 12 extra steps after the timed region"}
         if resident_value is not None:
             res["value_resident"] = resident_value
             res["value_with_fp32_h2d"] = fp32_value

@@ -1,0 +1,378 @@
+// SSDN_OP_CONV, 1x1 layers (the posterior head's NiN convolutions, noise_network.py:116-130 of the reference, and their data
+// gradients): out[p][m] = epi( sum_k in[p][k] * w[m][k] + bias[m] ) over P = N*H*W pixels -- a plain GEMM whose roofline is
+// HBM (every input pixel read once, every output written once: output_block.0 at batch 32 moves 2 x 100 MB for 38.6 GFLOP), so
+// the design goal is ONE pass over the input:
+//
+//   * a workgroup owns 256 consecutive pixels and ALL output channels of the layer (384: tile 256 x 384, eight waves of
+//     64 px x 192 ch = 12 accumulator tiles of 32x32; 96: eight waves of 32 px x 96 ch), so the activation tensor is fetched
+//     exactly once; the weight matrix (<= 288 KiB) streams from L2.
+//   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), 32 input channels per chunk: rows of 64 bytes, three
+//     stages in flight, one barrier per chunk.  A DMA instruction deposits 64 lanes x 16 B linearly, but every lane fetches from
+//     its own global address -- the 16-byte piece p of row r is stored at piece p ^ ((r >> 2) & 3), which makes every
+//     ds_read_b128 fragment read (32 rows x one K half) conflict-free (16-lane groups hit 16 distinct 16-byte slots).
+//   * per chunk a wave issues 2 x (WP + WM) ds_read_b128 and 2 x WP x WM MFMAs (32x32x16): 16 reads / 24 MFMAs for the 384 tile.
+//   * epilogue as in k_cdma: accumulators (initialised with the bias) -> LeakyReLU -> 16-bit, widened to 16-byte pieces with
+//     v_permlane32_swap, transposed through a wave-private LDS region, stored as pixel-contiguous runs; the data-gradient role
+//     multiplies by LeakyReLU'(saved activation) on the way out.
+#include "common.h"
+
+namespace {
+
+struct GdAux {
+    int nch;      // Ktot / 32
+    int ntiles;   // pixel tiles of TP
+    int lp;       // fused UNROT_BWD: log2 of the image side
+    // EPI bit 2: the launch is ALSO the following narrow 1x1 layer on its own output (the 9-channel net_out layer behind the 96-channel
+    // one): out32[n][m][pixel] = [lrelu](bias4[m] + sum_k w4[m][k] * out(pixel, k)), fp32 NCHW, from the rounded 16-bit tile in LDS
+    const h16* w4;      // packed [1][32][96]
+    const float* b4;    // or NULL
+    float* out32;
+    int M4, act4, HW;
+};
+
+__device__ __forceinline__ void gd_dma16(unsigned lds_addr, int voff, u32x4_t rs, int soff) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+}
+
+template <bool BF>
+__device__ __forceinline__ f32x16 gd_mma(half8 av, half8 bv, f32x16 c) {
+    if constexpr (BF)
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+}
+
+constexpr int GD_DA = 3, GD_DB = 3;
+constexpr int gd_eg(int wm) { return wm == 6 ? 2 : wm; }       // channel tiles per epilogue transpose group
+
+// wait until all but the newest n groups of PER DMA instructions of this wave have landed
+template <int PER>
+__device__ __forceinline__ void gd_wait_groups(int n) {
+    static_assert(3 * PER < 64, "vmcnt immediate");
+    if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER) : "memory");
+    else if (n == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PER) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * PER) : "memory");
+}
+
+}  // namespace
+
+// wave grid NWP (pixels) x NWM (channels); a wave owns WP x 32 pixels and WM x 32 output channels.  EPI bit 0: LeakyReLU' mask;
+// bit 2: the next narrow 1x1 layer computed from the output tile (GdAux.w4);
+// bit 1: fused SSDN_OP_UNROT_BWD (the 96-channel block r of a pixel goes, times LeakyReLU', to its place in rotation r's tensor).
+// PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the two operand rings run on as one chunk stream
+// across tile boundaries, so the loads of tile i+1 are in flight while tile i is converted and stored (the epilogue has its own
+// LDS region: wave-private transposes of EG channel tiles at a time).
+template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
+__global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, GdAux x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NW = NWP * NWM, TP = NWP * WP * 32, TM = NWM * WM * 32;
+    constexpr int ABYTES = TP * 64, BBYTES = TM * 64;
+    constexpr int DA = GD_DA, DB = GD_DB;                    // ring depths: activation chunks (HBM) / weight chunks (L2)
+    constexpr int NLA = NW / 2, NLB = NW - NLA;              // loader roles: waves [0, NLA) fetch activations, the rest weights --
+                                                             // vmcnt completes in order per WAVE: two streams, two counters
+    constexpr int NIA = TP / 16, NIB = TM / 16, PA = (NIA + NLA - 1) / NLA, PB = (NIB + NLB - 1) / NLB;
+    constexpr int EG = gd_eg(WM), NEG = WM / EG;             // epilogue: channel tiles per transpose group
+    constexpr int OSTR = EG * 64 + 16, NEK = EG * 2, CPP = EG * 4;
+    constexpr int BOFF = DA * ABYTES, EOFF = BOFF + DB * BBYTES, BIAS_OFF = EOFF + NW * 32 * OSTR, DUMMY_OFF = BIAS_OFF + TM * 4;
+    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0, OUT4 = (EPI & 4) != 0;
+    static_assert(!OUT4 || (NWM == 1 && WM == 3 && gd_eg(WM) == 3 && !BF), "the fused narrow layer needs the wave's whole 96-channel tile in its LDS region");
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = w / NWM, wm = w - wp * NWM;
+    const unsigned lds0 = (unsigned)(size_t)smem;
+    const int G = gridDim.x;
+    const int ntl = (x.ntiles - (int)blockIdx.x + G - 1) / G;        // tiles of this workgroup
+    const int total = ntl * x.nch;                                   // its chunk stream
+
+    const unsigned long long ap = (unsigned long long)a.src0.p, wgp = (unsigned long long)a.w;
+    const u32x4_t rs_a = {(unsigned)ap, (unsigned)(ap >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const u32x4_t rs_w = {(unsigned)wgp, (unsigned)(wgp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_um = __builtin_amdgcn_make_buffer_rsrc(a.unrot_mask.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+
+    // DMA lane constants: lane -> (row lane >> 2 of a 16-row instruction, LDS piece lane & 3); the piece fetched is the swizzled one
+    const int drow = lane >> 2, dpiece = (lane & 3) ^ ((drow >> 2) & 3);
+    const int voffA = (drow * a.src0.cs + dpiece * 8) * 2;
+    const int voffB = (drow * a.Ktot + dpiece * 8) * 2;
+    const bool loadA = w < NLA;
+    // loader state: the next chunk to issue is chunk lc of this workgroup's tile lt, into stage lst
+    int lt = 0, lc = 0, lst = 0, issued = 0;
+    auto issue_next = [&]() __attribute__((always_inline)) {
+        if (loadA) {
+            const int pix0 = ((int)blockIdx.x + lt * G) * TP;
+#pragma unroll
+            for (int u = 0; u < PA; ++u) {
+                const int i = w + NLA * u;              // wave-uniform
+                if (i < NIA) {
+                    const int soff = __builtin_amdgcn_readfirstlane((((pix0 + i * 16) * a.src0.cs) + a.src0.co + lc * 32) * 2);
+                    gd_dma16(lds0 + lst * ABYTES + i * 1024, voffA, rs_a, soff);
+                } else {
+                    // keep every loader's DMA count per chunk equal (one vmcnt immediate per role): an out-of-range fetch that
+                    // drops zeros into a scratch KiB
+                    gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+                }
+            }
+            lst = lst == DA - 1 ? 0 : lst + 1;
+        } else {
+#pragma unroll
+            for (int u = 0; u < PB; ++u) {
+                const int j = (w - NLA) + NLB * u;
+                if (j < NIB) {
+                    const int soff = __builtin_amdgcn_readfirstlane((j * 16 * a.Ktot + lc * 32) * 2);
+                    gd_dma16(lds0 + BOFF + lst * BBYTES + j * 1024, voffB, rs_w, soff);
+                } else {
+                    gd_dma16(lds0 + DUMMY_OFF, (int)0x80000000, rs_w, 0);
+                }
+            }
+            lst = lst == DB - 1 ? 0 : lst + 1;
+        }
+        ++issued;
+        if (++lc == x.nch) { lc = 0; ++lt; }
+    };
+    const int lead = loadA ? DA - 1 : DB - 1;
+    for (int c = 0; c < lead && c < total; ++c) issue_next();
+    float* bl = reinterpret_cast<float*>(smem + BIAS_OFF);
+    if (tid < TM) bl[tid] = (a.bias && tid < a.M) ? a.bias[tid] : 0.f;
+    half8 w4f[6];                         // OUT4: the narrow layer's weights, rows l31, K = 96 in six K-steps: registers for the whole launch
+    if constexpr (OUT4) {
+#pragma unroll
+        for (int ks = 0; ks < 6; ++ks) w4f[ks] = *reinterpret_cast<const half8*>(x.w4 + l31 * 96 + ks * 16 + (lane >> 5) * 8);
+    }
+    __syncthreads();
+
+    // fragment addresses: row l31 of a 32-row block, K half kh of K-step s -> piece (2s + kh) ^ ((l31 >> 2) & 3)
+    const int sw = (l31 >> 2) & 3;
+    const int fr0 = l31 * 64 + ((kh ^ sw) << 4), fr1 = l31 * 64 + (((2 + kh) ^ sw) << 4);
+    const int pbase = wp * WP * 2048, mbase = BOFF + wm * WM * 2048;
+    const float slope = a.act ? LRELU_SLOPE : 1.f;
+    char* reg = smem + EOFF + w * (32 * OSTR);
+
+    int ca = 0, cb = 0, done = 0;       // stages of the chunk being consumed; chunks consumed so far
+    for (int ti = 0; ti < ntl; ++ti) {
+        const int pix0 = ((int)blockIdx.x + ti * G) * TP;
+        f32x16 acc[WM][WP];
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 b4 = *reinterpret_cast<const float4*>(bl + (wm * WM + mt) * 32 + 8 * g + 4 * kh);
+#pragma unroll
+                for (int pt = 0; pt < WP; ++pt) {
+                    acc[mt][pt][4 * g + 0] = b4.x; acc[mt][pt][4 * g + 1] = b4.y; acc[mt][pt][4 * g + 2] = b4.z; acc[mt][pt][4 * g + 3] = b4.w;
+                }
+            }
+        // ---- chunks of this tile: chunk g sits in stages g % DA / g % DB; the loaders keep D-1 chunks ahead of `done` ----
+        for (int c = 0; c < x.nch; ++c) {
+            const int left = total - 1 - done;
+            if (loadA) gd_wait_groups<PA>(left < DA - 2 ? left : DA - 2);
+            else gd_wait_groups<PB>(left < DB - 2 ? left : DB - 2);
+            __syncthreads();
+            if (issued < total) issue_next();
+            const char* pa = smem + ca * ABYTES + pbase;
+            const char* pb = smem + cb * BBYTES + mbase;
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const int fr = s2 ? fr1 : fr0;
+                half8 pq[WP], wq[WM];
+#pragma unroll
+                for (int pt = 0; pt < WP; ++pt) pq[pt] = *reinterpret_cast<const half8*>(pa + pt * 2048 + fr);
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) wq[mt] = *reinterpret_cast<const half8*>(pb + mt * 2048 + fr);
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                    for (int pt = 0; pt < WP; ++pt) acc[mt][pt] = gd_mma<BF>(wq[mt], pq[pt], acc[mt][pt]);
+            }
+            ca = ca == DA - 1 ? 0 : ca + 1;
+            cb = cb == DB - 1 ? 0 : cb + 1;
+            ++done;
+        }
+        // ---- epilogue of the tile (wave-private; the rings keep filling meanwhile) ----
+#pragma unroll
+        for (int pt = 0; pt < WP; ++pt) {
+            const int pix_p = pix0 + (wp * WP + pt) * 32;
+#pragma unroll
+            for (int eg = 0; eg < NEG; ++eg) {
+                const int chb = wm * WM * 32 + eg * EG * 32;       // first channel of the group
+#pragma unroll
+                for (int me = 0; me < EG; ++me)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        const int mt = eg * EG + me;
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float v[4];
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                v[q] = acc[mt][pt][(2 * gp + h) * 4 + q];
+                                v[q] = fmaxf(v[q], slope * v[q]);
+                            }
+                            pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
+                            pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
+                        }
+                        u32x4_t o;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+                            o[d] = r[0]; o[2 + d] = r[1];
+                        }
+                        const int piece = me * 4 + 2 * gp + kh;
+                        *reinterpret_cast<u32x4_t*>(reg + l31 * OSTR + piece * 16) = o;
+                    }
+                if constexpr (OUT4) {
+                    // the narrow layer on the rounded tile just parked in LDS: D[m][pixel] = sum_k w4[m][k] * tile[pixel][k], k ascending on one
+                    // accumulator (the order of the separate launch: bit-identical), + bias, fp32 NCHW stores coalesced along the pixels
+                    f32x16 a4;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) a4[r] = 0.f;
+#pragma unroll
+                    for (int ks = 0; ks < 6; ++ks) {
+                        const half8 bq = *reinterpret_cast<const half8*>(reg + l31 * OSTR + (ks * 16 + kh * 8) * 2);
+                        a4 = gd_mma<false>(w4f[ks], bq, a4);
+                    }
+                    const int pix = pix_p + l31;
+                    const int n4 = pix / x.HW, rem = pix - n4 * x.HW;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = 8 * (r >> 2) + 4 * kh + (r & 3);
+                        if (m >= x.M4) continue;
+                        float v = a4[r];
+                        if (x.b4) v += x.b4[m];
+                        if (x.act4) v = lrelu(v);
+                        x.out32[((long long)n4 * x.M4 + m) * x.HW + rem] = v;
+                    }
+                }
+                // LDS -> HBM: 32 pixels x CPP 16-byte pieces, pixel-contiguous runs of EG * 64 bytes
+                u32x4_t mb[NEK];
+                int goff[NEK], loff[NEK];
+                bool live[NEK];
+#pragma unroll
+                for (int k = 0; k < NEK; ++k) {
+                    const int p = k * 64 + lane;
+                    const int px = p / CPP, c16 = (p - px * CPP) << 4;
+                    const int pix = pix_p + px;
+                    loff[k] = px * OSTR + c16;
+                    live[k] = true;
+                    if constexpr (UNROT) {
+                        // (b, i, j) of the pixel (H == W == P, a power of two), rotation r of the piece's 96-channel block
+                        const int lp = x.lp, P = 1 << lp;
+                        const int jx = pix & (P - 1), iy = (pix >> lp) & (P - 1), b = pix >> (2 * lp);
+                        const int ch = chb + (c16 >> 1);
+                        const int r = ch >= 288 ? 3 : (ch >= 192 ? 2 : (ch >= 96 ? 1 : 0)), cc = ch - r * 96;
+                        const int u = r == 0 ? iy : (r == 1 ? P - 1 - jx : (r == 2 ? P - 1 - iy : jx));
+                        const int v = r == 0 ? jx : (r == 1 ? iy : (r == 2 ? P - 1 - jx : P - 1 - iy));
+                        live[k] = u >= 1;                                  // u == 0: the shift cut it off -> zero row y = P-1
+                        const int dpix = (((((r * a.N + b) << lp) + (u >= 1 ? u - 1 : P - 1))) << lp) + v;
+                        goff[k] = (dpix * a.unrot.cs + a.unrot.co + cc) * 2;
+                        mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
+                    } else {
+                        goff[k] = (pix * a.dst.cs + a.dst.co + chb) * 2 + c16;
+                        if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + chb) * 2 + c16, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < NEK; ++k) {
+                    u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + loff[k]);
+                    if constexpr (UNROT) {
+                        if (!live[k]) o = u32x4_t{0u, 0u, 0u, 0u};
+                    }
+                    if constexpr (HAS_MASK || UNROT) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            float v0, v1;
+                            if constexpr (BF) { v0 = bf_lo(o[q]); v1 = bf_hi(o[q]); }
+                            else { v0 = f16_lo(o[q]); v1 = f16_hi(o[q]); }
+                            const int mlo = (int)(short)(mb[k][q] & 0xffffu), mhi = (int)mb[k][q] >> 16;
+                            v0 *= mlo > 0 ? 1.f : LRELU_SLOPE;
+                            v1 *= mhi > 0 ? 1.f : LRELU_SLOPE;
+                            o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
+                        }
+                    }
+                    if constexpr (UNROT) __builtin_amdgcn_raw_buffer_store_b128(o, rs_ur, goff[k], 0, 0);
+                    else __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+                }
+            }
+        }
+    }
+}
+
+// ---- host ----------------------------------------------------------------------------------------------------------------------
+bool gemm_dma_eligible(const ssdn_conv_args* a) {
+    if (a->ntaps != 1 || a->dy[0] || a->dx[0] || a->up0 || a->c1 || a->src1.p || a->dst32 || a->add.p) return false;
+    if (a->pool.p || a->upsum.p) return false;
+    if (a->unrot.p && (!a->bf16 || a->mask.p || a->Mpad != 384 || a->H != a->W || (a->H & (a->H - 1)) ||
+                       (long long)4 * a->N * a->H * a->W * a->unrot.cs * 2 >= (1ll << 31))) return false;
+    if (a->c0 != a->Ktot || a->Ktot % 32) return false;
+    if (a->M != a->Mpad || (a->Mpad != 384 && a->Mpad != 96)) return false;
+    const long long px = (long long)a->N * a->H * a->W;
+    if (px % 256) return false;
+    if (!a->bf16 && a->mask.p) return false;
+    int csmax = a->dst.cs > a->src0.cs ? a->dst.cs : a->src0.cs;
+    csmax = csmax > a->mask.cs ? csmax : a->mask.cs;
+    if (px * csmax * 2 >= (1ll << 31)) return false;
+    if ((a->src0.co & 7) || (a->src0.cs & 7)) return false;
+    return true;
+}
+
+int gemm_dma_lds_bytes(const ssdn_conv_args* a) {
+    const int tm = a->Mpad == 384 ? 384 : 96, eg = a->Mpad == 384 ? 2 : 3;
+    return GD_DA * 256 * 64 + GD_DB * tm * 64 + 8 * 32 * (eg * 64 + 16) + tm * 4 + 1024;
+}
+
+template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
+static int gd_launch(const ssdn_conv_args* a, hipStream_t s, const ssdn_conv_args* a4 = nullptr) {
+    constexpr int TP = NWP * WP * 32, TM = NWM * WM * 32;
+    constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + NWP * NWM * 32 * (gd_eg(WM) * 64 + 16) + TM * 4 + 1024;
+    static_assert(TP == 256 && NWP * NWM == 8, "gemm_dma_lds_bytes assumes 256-pixel tiles and 8 waves");
+    static_assert(LDS <= 160 * 1024, "LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_gdma<WP, WM, NWP, NWM, BF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    GdAux x;
+    x.nch = a->Ktot / 32;
+    x.lp = 0;
+    while ((1 << x.lp) < a->H) ++x.lp;
+    const double px = (double)a->N * a->H * a->W;
+    x.ntiles = (int)(px / TP);
+    x.w4 = nullptr; x.b4 = nullptr; x.out32 = nullptr; x.M4 = 0; x.act4 = 0; x.HW = a->H * a->W;
+    if (a4) { x.w4 = (const h16*)a4->w; x.b4 = a4->bias; x.out32 = a4->dst32; x.M4 = a4->M; x.act4 = a4->act; }
+    const int kreal = a->kreal > 0 ? a->kreal : a->Ktot;
+    prof_begin(SSDN_PROF_GEMM, s);
+    int cus = ssdn_device_cus();
+    if (cus <= 0) cus = 256;
+    const int grid = x.ntiles < cus ? x.ntiles : cus;           // persistent: one workgroup per CU (LDS-bound occupancy)
+    SSDN_LAUNCH((k_gdma<WP, WM, NWP, NWM, BF, EPI>), dim3(grid), dim3(64 * NWP * NWM), LDS, s, *a, x);
+    prof_end(SSDN_PROF_GEMM, s, 2.0 * px * a->M * kreal, px * (a->c0 + a->M) * 2.0);
+    SSDN_CHECK_HIP(hipGetLastError());
+    return 0;
+}
+
+int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s) {
+    const int epi = a->mask.p ? 1 : 0;
+    if (a->unrot.p) return gd_launch<2, 6, 4, 2, true, 2>(a, s);
+    if (a->Mpad == 384) {
+        if (!a->bf16) return gd_launch<2, 6, 4, 2, false, 0>(a, s);
+        return epi ? gd_launch<2, 6, 4, 2, true, 1>(a, s) : gd_launch<2, 6, 4, 2, true, 0>(a, s);
+    }
+    if (!a->bf16) return gd_launch<1, 3, 8, 1, false, 0>(a, s);
+    return epi ? gd_launch<1, 3, 8, 1, true, 1>(a, s) : gd_launch<1, 3, 8, 1, true, 0>(a, s);
+}
+
+// the narrow 1x1 layer `b` (net_out: <= 32 output channels, fp32 NCHW) directly behind the 96-channel 1x1 layer `a` can ride in a's launch
+bool gemm_dma_fuses_next(const ssdn_conv_args* a, const ssdn_conv_args* b) {
+    if (!gemm_dma_eligible(a) || a->bf16 || a->mask.p || a->unrot.p || a->Mpad != 96 || !a->dst.p) return false;
+    if (b->bf16 || b->ntaps != 1 || b->dy[0] || b->dx[0] || b->up0 || b->c1 || b->c0 != 96 || b->Ktot != 96 || b->Mpad != 32 || b->M > 32) return false;
+    if (!b->dst32 || b->mask.p || b->add.p || b->pool.p || b->upsum.p || b->unrot.p || !b->w) return false;
+    if (b->src0.p != a->dst.p || b->src0.cs != a->dst.cs || b->src0.co != a->dst.co) return false;
+    return b->N == a->N && b->H == a->H && b->W == a->W;
+}
+int launch_gemm_dma_with_next(const ssdn_conv_args* a, const ssdn_conv_args* b, hipStream_t s) {
+    if (!gemm_dma_fuses_next(a, b)) return ssdn_set_error("gemm: the second layer cannot ride in this launch");
+    return gd_launch<1, 3, 8, 1, false, 4>(a, s, b);
+}

@@ -106,12 +106,6 @@ struct WgAux {
 #define WG_ND 3                             // 64-lane loads per dZ row (<= 16 pixels x 12 chunks)
 #define WG_ONES_BYTES 4096                  // LDS area of bf16 1.0 behind the two images: B operand of the bias column
 
-// global -> LDS without registers (`buffer_load_dwordx4 ... lds`; see csrc/conv_dma.hip::dma16): M0 = LDS byte address of lane 0's 16
-// bytes, lane i lands at +16 i, lanes whose offset is outside the resource's num_records write zeros
-static __device__ __forceinline__ void wg_dma16(unsigned lds_addr, int voff, u32x4_t rs, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
-}
-
 // MFMA with the accumulator pinned to a register file.  A wave of this kernel owns up to 21 32x32 fp32 accumulators = 336
 // registers, more than the 256 AGPRs: the first 16 tiles live in AGPRs, the rest in VGPRs (the compiler will not split
 // them itself -- it spills instead).  The compiler does not know these asm statements are MFMAs, so it inserts no hazard
@@ -217,20 +211,6 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
         lod[i] = tx * g.DSTR + cc * 16;
     }
 
-    // dZ rows by LDS-DMA (static schedules): a row of the LDS image is TW pixels x DSTR bytes = TW * DSTR / 16 pieces, contiguous,
-    // fetched by WG_ND 64-lane instructions; piece q = lane + 64 i is (pixel q / ppx, 16-byte piece q % ppx), pieces past the real
-    // channels (and past the row) get an offset outside the resource: zeros
-    int dvoff[WG_ND];
-    {
-        const int ppx = g.DSTR >> 4;
-#pragma unroll
-        for (int i = 0; i < WG_ND; ++i) {
-            const int q = lane + 64 * i;
-            const int tx = q / ppx, cc = q - tx * ppx;
-            dvoff[i] = (tx < g.TW && cc < x.ccd) ? (tx * a.dz.cs + a.dz.co + cc * 8) * 2 : 0x40000000;
-        }
-    }
-    const unsigned lds0 = (unsigned)(size_t)smem;
 #ifdef SSDN_TUNING
     int tr_i = 0;
     auto stamp = [&]() {
@@ -510,45 +490,32 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
             // wave whose row index is past the tile (the row count need not divide by 4) loads zeros and writes them to the
             // image's dummy row.
             // BOTH (wide rows, 1x1 layers): K-step ks loads input row ks AND dZ row ks, prefetch distance 2.
-            // !BOTH (round 4): the dZ rows of the next tile arrive by LDS-DMA, issued at the head of K-step 0 (the oldest requests of
-            // the tile: vmcnt completes in order, so the input rows' waits cover them) -- no registers, no LDS stores, and the input
-            // rows' prefetch distance grows from 3 K-steps to KS - RWX (5 of 8): under full-chip load a row's latency exceeds 3
-            // K-steps (per-tile time 3.1 us on a quiet chip, 4.9 us with every CU streaming).
             const int xsx = ((x0 >> sh) * scs) * 2, xsd = x0 * a.dz.cs * 2;
-            constexpr bool DZDMA = !BOTH;
-            constexpr int DIST = BOTH ? 2 : (RWX <= 3 ? KS - RWX : 3);   // K-steps between a row's loads and its LDS writes
-            constexpr int NSET = BOTH ? 2 : 3;          // prefetch register sets
+            constexpr int DIST = BOTH ? 2 : 3;          // K-steps between a row's loads and its LDS writes
             constexpr int DO = BOTH ? NL : 0;           // first dZ piece inside a prefetch register set
-            static_assert((BOTH ? (RWX > RWD ? RWX : RWD) : (DZDMA ? RWX : RWX + RWD)) + DIST <= KS, "row items must be committed within their tile");
-            static_assert(WG_ND * 64 >= 16 * 12, "a dZ row is at most 16 pixels x 12 pieces");
+            static_assert((BOTH ? (RWX > RWD ? RWX : RWD) : RWX + RWD) + DIST <= KS, "row items must be committed within their tile");
             static_for<0, KS>([&](auto Kc) __attribute__((always_inline)) {
                 constexpr int ks = decltype(Kc)::value;
                 constexpr int kc = ks - DIST;               // the K-step whose loads are written to LDS now
                 constexpr bool LX = BOTH ? ks < RWX : ks < RWX;                              // loaded in this K-step
-                constexpr bool LD = BOTH ? ks < RWD : (!DZDMA && ks >= RWX && ks < RWX + RWD);
+                constexpr bool LD = BOTH ? ks < RWD : (ks >= RWX && ks < RWX + RWD);
                 constexpr bool CX = kc >= 0 && (BOTH ? kc < RWX : kc < RWX);                 // committed in this K-step
-                constexpr bool CD = kc >= 0 && (BOTH ? kc < RWD : (!DZDMA && kc >= RWX && kc < RWX + RWD));
+                constexpr bool CD = kc >= 0 && (BOTH ? kc < RWD : (kc >= RWX && kc < RWX + RWD));
                 constexpr int rsx = ks, rsd = BOTH ? ks : ks - RWX;                          // row slots of the loads
                 half8* afc = (ks & 1) ? afB : afA;
                 half8* afn = (ks & 1) ? afA : afB;
-                // (a set is loaded at K-step ks and committed at ks + DIST; never both in one K-step unless DIST == NSET)
-                constexpr int si = (LX || LD) ? ks % NSET : (kc >= 0 ? kc % NSET : 0);
-                half8* pv = si == 0 ? pvA : si == 1 ? pvB : pvC;
-                int& rox = si == 0 ? rlA : si == 1 ? rlB : rlC;   // LDS byte offsets (inside an image) of the set's rows
-                int& rod = si == 0 ? rdA : si == 1 ? rdB : rdC;
+                half8* pv = ks % DIST == 0 ? pvA : ks % DIST == 1 ? pvB : pvC;
+                int& rox = ks % DIST == 0 ? rlA : ks % DIST == 1 ? rlB : rlC;   // LDS byte offsets (inside an image) of the set's rows
+                int& rod = ks % DIST == 0 ? rdA : ks % DIST == 1 ? rdB : rdC;
                 constexpr int kn = (ks + 1) % KS;
                 const char* ab = abase(kn);
                 const char* xb = xbase(kn);
                 const h16* nbx = dzp;
                 const h16* nbd = dzp;
                 int nnx = 0, nnd = 0;
-                u32x4_t drs = {0u, 0u, 0u, SSDN_BUFFER_RSRC_FLAGS};
-                unsigned dlds = 0;
-                // side items in issue order: LDS-DMA of the dZ rows (K-step 0), LDS writes of the old rows, then description + loads
-                // of the new rows
-                constexpr int NDM = (DZDMA && ks == 0) ? RWD * (WG_ND + 1) : 0;
+                // side items in issue order: LDS writes of the old rows, then description + loads of the new rows
                 constexpr int NCX = CX ? NL : 0, NCD = CD ? WG_ND : 0, NLX = LX ? NL + 1 : 0, NLD = LD ? WG_ND + 1 : 0;
-                constexpr int NSIDE = NDM + NCX + NCD + NLX + NLD;
+                constexpr int NSIDE = NCX + NCD + NLX + NLD;
                 constexpr int SLOTS = MT * CPW;
                 static_for<0, SLOTS>([&](auto Sc) __attribute__((always_inline)) {
                     constexpr int S = decltype(Sc)::value, j = S / MT, mt = S % MT;
@@ -558,32 +525,14 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
                         bf[j] = read_b(xb, j);
                     }
                     static_for<0, NSIDE>([&](auto Wc) __attribute__((always_inline)) {
-                        constexpr int w0 = decltype(Wc)::value;
-                        constexpr int sl = SLOTS - MT >= NSIDE ? MT + w0 * (SLOTS - MT) / NSIDE : MT + (w0 * (SLOTS - MT)) / NSIDE;
+                        constexpr int w = decltype(Wc)::value;
+                        constexpr int sl = SLOTS - MT >= NSIDE ? MT + w * (SLOTS - MT) / NSIDE : MT + (w * (SLOTS - MT)) / NSIDE;
                         if constexpr (sl == S) {
-                            if constexpr (w0 < NDM) {
-                                constexpr int r = w0 / (WG_ND + 1), u = w0 % (WG_ND + 1) - 1;
-                                if constexpr (u < 0) {
-                                    const int row = wave + WG_WAVES * r;
-                                    const bool valid = row < g.TH;
-                                    const int y = y0 + row;
-                                    const bool ok = more && valid && y < a.H;
-                                    const unsigned long long bp = (unsigned long long)(dzp + (long long)((n0 * a.H + y) * a.W) * a.dz.cs);
-                                    drs[0] = (unsigned)bp;
-                                    drs[1] = (unsigned)(bp >> 32) & 0xffffu;
-                                    drs[2] = ok ? (unsigned)(a.W * a.dz.cs * 2) : 0u;
-                                    dlds = lds0 + (unsigned)(img_n - smem) + (unsigned)(g.XB + (valid ? row : g.TH) * g.TW * g.DSTR);
-                                } else {
-                                    if (more) wg_dma16(dlds + u * 1024, dvoff[u], drs, xsd);
-                                }
-                            } else if constexpr (w0 - NDM < NCX) {
-                                constexpr int w = w0 - NDM;
+                            if constexpr (w < NCX) {
                                 put_x(img_n, rox, w, pv[w]);
-                            } else if constexpr (w0 - NDM < NCX + NCD) {
-                                constexpr int w = w0 - NDM;
+                            } else if constexpr (w < NCX + NCD) {
                                 put_d(img_n, rod, w - NCX, pv[DO + w - NCX]);
-                            } else if constexpr (w0 - NDM < NCX + NCD + NLX) {
-                                constexpr int w = w0 - NDM;
+                            } else if constexpr (w < NCX + NCD + NLX) {
                                 constexpr int u = w - NCX - NCD - 1;
                                 if constexpr (u < 0) {
                                     const int row = wave + WG_WAVES * rsx;
@@ -599,7 +548,6 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
                                     pv[u] = load16(nrow, relx[u]);
                                 }
                             } else {
-                                constexpr int w = w0 - NDM;
                                 constexpr int u = w - NCX - NCD - NLX - 1;
                                 if constexpr (u < 0) {
                                     const int row = wave + WG_WAVES * rsd;
@@ -620,7 +568,6 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
                     __builtin_amdgcn_sched_barrier(0);
                 });
             });
-            if constexpr (DZDMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's dZ rows have landed (barrier below)
         } else {
 #pragma unroll 1
             for (int ks = 0; ks < ksteps; ks += 2) {   // ksteps is even (tiles have >= 32 pixels)
@@ -655,16 +602,6 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
     }
 }
 
-// algorithmic flops of one op: 2 * pixels * output channels * input channels per tap * taps.  The "taps" of a 1x1 head layer are
-// 96-channel blocks of its input (coff[t]): every tap multiplies M x Kpad, not M x Ktot (the staged width)
-static inline double wgrad_flops(const ssdn_wgrad_args* a) {
-    bool blocks = a->ntaps > 1;
-    for (int t = 0; t < a->ntaps; ++t) blocks = blocks && a->dy[t] == 0 && a->dx[t] == 0;
-    const double px = (double)a->N * a->H * a->W;
-    const int mb = a->mblocks > 1 ? a->mblocks : 1;
-    const int kt = blocks ? (a->Kpad < a->Ktot ? a->Kpad : a->Ktot) : a->Ktot;
-    return 2.0 * px * a->M * mb * kt * a->ntaps;
-}
 static int wgrad_validate(const ssdn_wgrad_args* a) {
     if (a->ntaps < 1 || a->ntaps > SSDN_MAX_TAPS) return ssdn_set_error("wgrad: ntaps out of range");
     if (a->ltw + a->lth + a->ltn > 8 || a->ltw + a->lth + a->ltn < 5) return ssdn_set_error("wgrad: tile must have 32..256 pixels");

@@ -38,12 +38,21 @@ typedef const __attribute__((address_space(4))) WgMegaEntry* WgMegaEntryC;
 typedef const __attribute__((address_space(4))) WgMegaItem* WgMegaItemC;
 // The register allocation of this kernel sits on an edge (the 21-accumulator bodies use 480+ of the 512 registers): one more kernel
 // argument once flipped it from 0 to 764 spilled VGPRs.  `make` therefore checks the code object (check_scratch.py): a build whose
-// weight-gradient kernels need scratch FAILS.  Block timeline for tools/wgrad_calib.py (ssdn_debug_set_trace): the buffer's address
-// travels in the entry table (WgAux.trace) and is loaded at the end of the block, where both stamps are written; s_memrealtime is
-// the chip-wide 100 MHz clock (s_memtime counts per XCD).
-__global__ __launch_bounds__(WG_THREADS) void k_wgrad_mega(const WgMegaEntry* __restrict__ ent, const WgMegaItem* __restrict__ items) {
-    const unsigned long long t_start = __builtin_amdgcn_s_memrealtime();     // (both stamps are STORED at the end: a store in front of the
-                                                                              //  body would cost its table loads their invariance)
+// weight-gradient kernels need scratch FAILS.  Block timeline for tools/wgrad_calib.py: only in `make TUNING=1` builds.
+#ifdef SSDN_TUNING
+#define WG_MEGA_TRACE_PARAM , unsigned long long* __restrict__ trace
+#define WG_MEGA_TRACE_ARG , (unsigned long long*)ssdn_debug_get_trace()
+#else
+#define WG_MEGA_TRACE_PARAM
+#define WG_MEGA_TRACE_ARG
+#endif
+__global__ __launch_bounds__(WG_THREADS) void k_wgrad_mega(const WgMegaEntry* __restrict__ ent, const WgMegaItem* __restrict__ items WG_MEGA_TRACE_PARAM) {
+#ifdef SSDN_TUNING
+    if (trace && threadIdx.x == 0) {      // {start, end, entry | bx << 16} per block, s_memtime ticks
+        trace[3 * blockIdx.x] = __builtin_amdgcn_s_memtime();
+        trace[3 * blockIdx.x + 2] = (unsigned long long)items[blockIdx.x].entry | ((unsigned long long)items[blockIdx.x].bx << 16);
+    }
+#endif
     const WgMegaItemC it = (WgMegaItemC)(unsigned long long)(items + blockIdx.x);
     const WgMegaEntryC E4 = (WgMegaEntryC)(unsigned long long)(ent + it->entry);
     const unsigned bx = (unsigned)it->bx, by = (unsigned)it->by;
@@ -58,14 +67,9 @@ __global__ __launch_bounds__(WG_THREADS) void k_wgrad_mega(const WgMegaEntry* __
         case 103: wgrad_thin_body<3>(E.a, bx, gx); break;
         default: break;
     }
-    {
-        unsigned long long* tr = E.x.trace;
-        if (tr && threadIdx.x == 0) {      // {start, end, entry | bx << 16} per block
-            tr[3 * blockIdx.x] = t_start;
-            tr[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
-            tr[3 * blockIdx.x + 2] = (unsigned long long)it->entry | ((unsigned long long)bx << 16);
-        }
-    }
+#ifdef SSDN_TUNING
+    if (trace && threadIdx.x == 0) trace[3 * blockIdx.x + 1] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // the template instance launch_wgrad runs an op with (the WG_CASE dispatch below, as data)
@@ -158,7 +162,7 @@ int launch_wgrad_mega(const ssdn_wgrad_args* const* ops, int n, hipStream_t s) {
         const double px = (double)ops[i]->N * ops[i]->H * ops[i]->W;
         const int mb = ops[i]->mblocks > 1 ? ops[i]->mblocks : 1;
         const bool thin = e.inst >= 100;
-        flops += thin ? 2.0 * px * ops[i]->M * ops[i]->kreal * ops[i]->ntaps : wgrad_flops(ops[i]);
+        flops += 2.0 * px * ops[i]->M * mb * (thin ? ops[i]->kreal : ops[i]->Ktot) * ops[i]->ntaps;
         bytes += px * 2.0 * (ops[i]->M * mb + (thin ? ops[i]->kreal : ops[i]->Ktot));
         const double c = ops[i]->cost > 0.f ? (double)ops[i]->cost : 1.0;
         for (int by = 0; by < p.gy; ++by)
@@ -206,7 +210,7 @@ int launch_wgrad_mega(const ssdn_wgrad_args* const* ops, int n, hipStream_t s) {
     }
     if (lds > 160 * 1024) return ssdn_set_error("wgrad: merged launch needs %zu B of LDS", lds);
     prof_begin(SSDN_PROF_WGRAD, s);
-    SSDN_LAUNCH(k_wgrad_mega, dim3((unsigned)items.size()), dim3(WG_THREADS), lds, s, (const WgMegaEntry*)dtab, (const WgMegaItem*)(dtab + off_items));
+    SSDN_LAUNCH(k_wgrad_mega, dim3((unsigned)items.size()), dim3(WG_THREADS), lds, s, (const WgMegaEntry*)dtab, (const WgMegaItem*)(dtab + off_items) WG_MEGA_TRACE_ARG);
     prof_end(SSDN_PROF_WGRAD, s, flops, bytes);
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;

@@ -72,7 +72,7 @@ static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& 
     const int gy = a->csplit > 1 ? a->csplit : 1;
     const int gx = a->mblocks > 1 ? ((a->nslabs + 7) / 8) * 8 * a->mblocks : a->nslabs;
     hipLaunchKernelGGL((k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>), dim3(gx, gy), dim3(WG_THREADS), lds, s, *a, x);
-    prof_end(SSDN_PROF_WGRAD, s, wgrad_flops(a), px * 2.0 * (a->M * (a->mblocks > 1 ? a->mblocks : 1) + a->Ktot));
+    prof_end(SSDN_PROF_WGRAD, s, 2.0 * px * a->M * a->Ktot * a->ntaps, px * 2.0 * (a->M + a->Ktot));
     return 0;
 }
 
@@ -138,7 +138,7 @@ int launch_wgrad_multi(const ssdn_wgrad_args* const* items, int n, hipStream_t s
         blocks += p.gx * p.gy;
         lds = p.lds > lds ? p.lds : lds;
         const double px = (double)items[i]->N * items[i]->H * items[i]->W;
-        flops += wgrad_flops(items[i]);
+        flops += 2.0 * px * items[i]->M * items[i]->Ktot * items[i]->ntaps;
         bytes += px * 2.0 * (items[i]->M + items[i]->Ktot);
     }
     int dev = 0;

@@ -32,12 +32,14 @@ WGRAD_MEGA = "all"
 # cost model of one weight-gradient block, in cycles (calibrated on BASELINE config 2 with tools/wgrad_calib.py):
 #   K-step of 16 pixels = base + per_mfma * MT * CPW;  a block = tiles * ksteps * K-step + fixed + slab bytes / slab_rate
 MEGA_COST = {
-    "static": (300.0, 24.0),      # compile-time staging schedules (3x3 layers, 16x8-pixel tiles)
-    "generic": (1000.0, 33.0),    # run-time staging (small layers, odd tiles)
-    "head": (800.0, 0.0),         # 1x1 layers over four 96-channel input blocks (an input AND a dZ row per K-step)
-    "head_mb": (800.0, 0.0),      # ... with the 4 output blocks of a pixel partition side by side (input shared through L2)
-    "thin": (1900.0, 450.0),      # k_wgrad_thin: per 256-pixel tile: base + per 32 output channels
-    "fixed": 6000.0,              # prologue (first tile fetched synchronously) + item switch
+    # measured INSIDE the chip-wide launch of BASELINE config 2 (every CU streaming; tools/wgrad_calib.py trace: per-block
+    # s_memrealtime stamps), in cycles of a nominal 2.1 GHz clock.  On a quiet chip the same blocks run ~1.45x faster.
+    "static": (342.0, 38.8),      # compile-time staging schedules (3x3 layers, 16x8-pixel tiles): 4.4 us per (3,7) tile
+    "generic": (1350.0, 53.0),    # run-time staging (small layers, odd tiles)
+    "head": (1208.0, 0.0),        # 1x1 layers over four 96-channel input blocks (an input AND a dZ row per K-step)
+    "head_mb": (1208.0, 0.0),     # ... with the 4 output blocks of a pixel partition side by side (input shared through L2)
+    "thin": (2211.0, 963.0),      # k_wgrad_thin: per 256-pixel tile: base + per 32 output channels
+    "fixed": 30000.0,             # prologue (first tile fetched synchronously), launch ramp
     "slab_rate": 10.0,            # bytes per cycle a workgroup writes its slab with
 }
 TAPS_BLIND = [(ky - 2, kx - 1) for ky in range(3) for kx in range(3)]   # ShiftConv2d: in[y+ky-2, x+kx-1]

@@ -56,7 +56,7 @@ def main():
     print("slab reductions: %.1f us" % time_list(red))
 
 
-if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("subsets", "trace", "load")):
+if __name__ == "__main__" and not (len(sys.argv) > 1 and sys.argv[1] in ("subsets", "trace", "load", "mega_only")):
     main()
 
 
@@ -85,7 +85,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "subsets":
 
 
 def trace():
-    """per-block timeline of the chip-wide launch from the s_memtime stamps of k_wgrad_mega (100 MHz ticks)"""
+    """per-block timeline of the chip-wide launch from the s_memrealtime stamps of k_wgrad_mega (100 MHz)"""
     import ctypes as C
     import numpy as np
     B, P = 32, 64
@@ -112,6 +112,10 @@ def trace():
     t0 = t[:, 0].min()
     tick = 0.01        # us per s_memtime tick (100 MHz constant clock)
     print("blocks %d; launch span %.1f us; last start %.1f us" % (len(t), (t[:, 1].max() - t0) * tick, (t[:, 0].max() - t0) * tick))
+    ends = np.sort((t[:, 1] - t0) * tick)
+    print("CU-time used %.0f us x CU of %.0f available (%.1f %%); block end times: 10%% %.0f, 50%% %.0f, 90%% %.0f, max %.0f us" % (
+        ((t[:, 1] - t[:, 0]) * tick).sum(), 256 * ends[-1], 100 * ((t[:, 1] - t[:, 0]) * tick).sum() / (256 * ends[-1]),
+        ends[len(ends) // 10], ends[len(ends) // 2], ends[9 * len(ends) // 10], ends[-1]))
     for e, op in enumerate(ops):
         sel = t[(t[:, 2] & 0xffff) == e]
         if not len(sel):
@@ -169,3 +173,30 @@ def load():
 
 if len(sys.argv) > 1 and sys.argv[1] == "load":
     load()
+
+
+def mega_only():
+    """a few chip-wide launches + reductions, nothing else (for rocprofv3 --pmc passes: tools/pmc_mega.sh)"""
+    B, P = 32, 64
+    cus = L.load().ssdn_device_cus()
+    plan = NetPlan("m/", 3, 9, True, B, P, P, cus=cus)
+    dev = torch.device("cuda:0")
+    flat = torch.randn(plan.nparams, device=dev) * 0.05
+    dn = DeviceNet(plan, dev, flat, torch.zeros_like(flat))
+    for name, t in dn.t.items():
+        if t.dtype in (torch.float16, torch.bfloat16):
+            t.copy_(torch.randn(t.shape, device=dev) * 0.5)
+    ops = [op for op in plan.bwd if op.type == "wgrad"]
+    ol = OpList([dn._mat(op) for op in ops])
+    red = OpList([dn._mat(op) for op in plan.bwd if op.type == "wreduce"])
+    big = [OpList([dn._mat(op)]) for op in ops if op.a["layer"] in ("decode_block_1.2", "output_block.0", "encode_block_1.2")]
+    for _ in range(4):
+        ol.run(current_stream())
+        red.run(current_stream())
+    for o in big:
+        o.run(current_stream())
+    torch.cuda.synchronize()
+
+
+if len(sys.argv) > 1 and sys.argv[1] == "mega_only":
+    mega_only()
