@@ -54,6 +54,60 @@ def make_cfg():
     return cfg
 
 
+def trainer_leg(B, P, steps, workers=8, warm=30):
+    """patches/s of `ssdn train` itself: DenoiserTrainer.train() on an HDF5 file (h5lite.write_dataset_file: 160 images of
+    3 x 375 x 500, the size class of the reference's ImageNet validation crops), `workers` DataLoader processes, metrics on."""
+    import logging
+    import shutil
+    import tempfile
+    import numpy as np
+    import ssdn
+    from ssdn.datasets import h5lite
+    from ssdn.params import ConfigValue
+    from ssdn.train import DenoiserTrainer
+    tmp = tempfile.mkdtemp(prefix="ssdn_bench_")
+    try:
+        rng = np.random.default_rng(7)
+        path = os.path.join(tmp, "train.h5")
+        h5lite.write_dataset_file(path, [rng.integers(0, 256, size=(3, 375, 500), dtype=np.uint8) for _ in range(160)])
+        cfg = make_cfg()
+        cfg[ConfigValue.TRAIN_MINIBATCH_SIZE] = B
+        cfg[ConfigValue.TRAIN_PATCH_SIZE] = P
+        cfg[ConfigValue.TRAIN_DATA_PATH] = path
+        cfg[ConfigValue.TEST_DATA_PATH] = None
+        cfg[ConfigValue.TRAIN_ITERATIONS] = (warm + steps) * B
+        cfg[ConfigValue.PRINT_INTERVAL] = 50 * B
+        cfg[ConfigValue.EVAL_INTERVAL] = cfg[ConfigValue.SNAPSHOT_INTERVAL] = 10 ** 9
+        cfg[ConfigValue.DATALOADER_WORKERS] = workers
+        ssdn.cfg.infer(cfg)
+        tr = DenoiserTrainer(cfg, runs_dir=tmp)
+        tr.new_target()
+        d = tr.denoiser
+        inner = d.train_step
+        marks = {"n": 0}
+
+        def timed_step(*a, **kw):
+            if marks["n"] == warm:
+                torch.cuda.synchronize()
+                marks["t0"] = time.perf_counter()
+            out = inner(*a, **kw)
+            marks["n"] += 1
+            if marks["n"] == warm + steps:
+                torch.cuda.synchronize()
+                marks["t1"] = time.perf_counter()
+            return out
+        d.train_step = timed_step
+        logging.getLogger("ssdn").setLevel(logging.WARNING)
+        tr.train()
+        dt = marks["t1"] - marks["t0"]
+        hist = tr.state[ssdn.params.StateValue.HISTORY][ssdn.params.HistoryValue.TRAIN]
+        return round(steps * B / dt, 2), {"steps": steps, "warmup_steps": warm, "dataloader_workers": workers, "ms_per_step": round(1e3 * dt / steps, 4),
+                                          "images": "160 x (3, 375, 500) uint8, HDF5 (dataset_tool_h5 layout)", "metrics": "on (device accumulators, read at PRINT_INTERVAL = 50 steps)",
+                                          "logged_metrics": sorted(k for k in hist if k != "n")}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def synth_batch(B, P, seed, device):
     g = torch.Generator().manual_seed(seed)
     clean = torch.rand((B, 3, P, P), generator=g)
@@ -329,6 +383,13 @@ def run_rank(args):
                           {MD.INPUT_NOISE_VALUES: hb[2].to(device, non_blocking=True), MD.CLEAN: clean}], 3e-4, exchange)
         fp32_value = timed(fp32_step)
 
+    # (c) the REAL trainer end to end (N = 1): `DenoiserTrainer.train()` over a synthetic HDF5 file written in the reference
+    # converter's layout -- forked DataLoader workers cropping at read (uint8), pinned upload, device noise, training step, the
+    # per-step metrics on the device, console / scalar logging at PRINT_INTERVAL.  Timed from step TR_WARM to the last step.
+    trainer_value = trainer_info = None
+    if world == 1 and not stub and not args.no_trainer_leg:
+        trainer_value, trainer_info = trainer_leg(B, P, max(200, args.steps), workers=args.trainer_workers)
+
     if rank == 0:
         value = args.steps * B * world / dt
         achieved = (fl.value / 1e12) / (ms.value / 1e3) if ms.value > 0 else 0.0
@@ -384,6 +445,9 @@ def run_rank(args):
             res["value_resident"] = resident_value
             res["value_with_fp32_h2d"] = fp32_value
             res["side_leg_steps"] = SIDE_STEPS
+        if trainer_value is not None:
+            res["value_trainer_hdf5"] = trainer_value
+            res["trainer_hdf5"] = trainer_info
         if world == 1 and not args.no_cpu_baseline and not stub:
             res["cpu_baseline"] = cpu_baseline(P)
         print(json.dumps(res))
@@ -400,6 +464,8 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="patches per GPU")
     ap.add_argument("--patch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trainer-leg", action="store_true", help="skip the value_trainer_hdf5 side leg (DenoiserTrainer.train() over an HDF5 file)")
+    ap.add_argument("--trainer-workers", type=int, default=8)
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args))

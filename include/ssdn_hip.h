@@ -35,7 +35,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SSDN_ABI_VERSION 8
+#define SSDN_ABI_VERSION 9
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -63,7 +63,7 @@ enum ssdn_op_type {
     SSDN_OP_MSE = 15,
     SSDN_OP_MASK_MSE = 16,
     SSDN_OP_ADAM = 17,
-    SSDN_OP_SQERR = 18,
+    SSDN_OP_METRICS = 18,  /* per-step loss / PSNR / std-dev sums into a device-resident accumulator (H11) */
     SSDN_OP_ZERO = 19,
     SSDN_OP_EVENT_RECORD = 20, /* hipEventRecord(event) on the op's lane: lets a consumer outside the list (the gradient
                                   all-reduce on its own stream) wait for a PREFIX of the list */
@@ -362,13 +362,30 @@ typedef struct ssdn_adam_args {
     float gscale; /* multiplies g first (1/world_size for data parallel) */
 } ssdn_adam_args;
 
-/* per-sample sum of squared error (PSNR numerator, utils/data.py:94-105): dst[b] = mean_{chw} (a-b)^2 */
-typedef struct ssdn_sqerr_args {
-    const float* a;
-    const float* b;
-    float* dst;
-    int32_t B, n; /* n = C*H*W */
-} ssdn_sqerr_args;
+/* ---- SSDN_OP_METRICS ------------------------------------------------------------------------
+ * H11: the per-step metric accumulation of the trainer / evaluator (reference train.py:205-218,553-584, utils/data.py:94-105 with
+ * utils/utils.py Metric.add) as ONE launch that adds into a device-resident accumulator; the host reads the 16 floats back when it
+ * prints (PRINT_INTERVAL), not every step.  Per sample b, over the valid extent ext[b] = (e1, e2) of the two spatial axes (NULL:
+ * the whole image -- evaluation batches are padded, metadata IMAGE_SHAPE):
+ *     psnr_x[b]   = -10 log10( mean_{c, i < e1, j < e2} (x[b,c,i,j] - clean[b,c,i,j])^2 )     x = out (IMG_DENOISED), mu (IMG_MU)
+ *     mstd[b]     = 255 * mean_{i,j} model_std[b,i,j]          nstd[b] = 255 * noise_std[b] (or its mean over the pixels)
+ * and acc[2k] += sum_b value_k[b], acc[2k+1] += count_k for k = 0..4 = loss, psnr_out, psnr_mu, noise_std, model_std (count = B; 1
+ * for a noise_std that is one value for the whole batch) -- exactly what `Metric.add` of the reference accumulates (sum over the
+ * samples of the per-sample value, sample count).  Deterministic: per-sample values go through `per`, the block that arrives last
+ * (ticket in acc[15]) adds them in sample order.  NULL inputs are skipped. */
+typedef struct ssdn_metrics_args {
+    const float* out;       /* [B,C,H,W] or NULL */
+    const float* mu;        /* [B,C,H,W] or NULL */
+    const float* clean;     /* [B,C,H,W] */
+    const float* loss;      /* [B] or NULL */
+    const float* model_std; /* [B,H,W] or NULL */
+    const float* noise_std; /* [noise_n] values (noise_n = 1, B or B*H*W) or NULL */
+    const int32_t* ext;     /* [B][2] or NULL */
+    int32_t B, C, H, W;
+    int32_t noise_n;
+    float* per;             /* scratch [B][8] */
+    float* acc;             /* [16] accumulator (the host zeroes it when it resets its metrics) */
+} ssdn_metrics_args;
 
 typedef struct ssdn_zero_args {
     void* p;

@@ -85,7 +85,7 @@ int ssdn_struct_size(int op_type) {
         case SSDN_OP_SPATIAL_MEAN: return (int)sizeof(ssdn_spatial_mean_args);
         case SSDN_OP_MSE: case SSDN_OP_MASK_MSE: return (int)sizeof(ssdn_mse_args);
         case SSDN_OP_ADAM: return (int)sizeof(ssdn_adam_args);
-        case SSDN_OP_SQERR: return (int)sizeof(ssdn_sqerr_args);
+        case SSDN_OP_METRICS: return (int)sizeof(ssdn_metrics_args);
         case SSDN_OP_ZERO: return (int)sizeof(ssdn_zero_args);
         case SSDN_OP_EVENT_RECORD: return (int)sizeof(ssdn_event_args);
         case SSDN_OP_NOISE: return (int)sizeof(ssdn_noise_args);
@@ -327,7 +327,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
                 } else rc = launch_adam((const ssdn_adam_args*)p, s);
                 break;
             }
-            case SSDN_OP_SQERR: rc = launch_sqerr((const ssdn_sqerr_args*)p, s); break;
+            case SSDN_OP_METRICS: rc = launch_metrics((const ssdn_metrics_args*)p, s); break;
             case SSDN_OP_NOISE: rc = launch_noise((const ssdn_noise_args*)p, s); break;
             case SSDN_OP_ZERO: {
                 const ssdn_zero_args* z = (const ssdn_zero_args*)p;

@@ -131,7 +131,7 @@ int launch_adam(const ssdn_adam_args* a, hipStream_t s);
 #define ADAM_PACK_MAX 24
 int adam_pack_fusable(const ssdn_adam_args* a, const ssdn_wpack_args* const* items, int n);
 int launch_adam_pack(const ssdn_adam_args* a, const ssdn_wpack_args* const* items, int n, hipStream_t s);
-int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s);
+int launch_metrics(const ssdn_metrics_args* a, hipStream_t s);
 int launch_noise(const ssdn_noise_args* a, hipStream_t s);
 int conv_lds_bytes(const ssdn_conv_args* a);
 int conv_validate(const ssdn_conv_args* a);                     // conv_mfma.hip: argument checks shared by every conv launcher

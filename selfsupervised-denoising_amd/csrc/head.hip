@@ -312,18 +312,63 @@ int launch_mse(const ssdn_mse_args* a, int masked, hipStream_t s) {
     return 0;
 }
 
-__global__ void k_sqerr(ssdn_sqerr_args a) {
+// H11 (SSDN_OP_METRICS): one block per sample; the block that arrives last adds the per-sample values in sample order
+__global__ void k_metrics(ssdn_metrics_args a) {
     __shared__ float sh[4];
-    int b = blockIdx.x;
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < a.n; i += HB) {
-        float d = a.a[(long long)b * a.n + i] - a.b[(long long)b * a.n + i];
-        acc += d * d;
+    __shared__ int last;
+    const int b = blockIdx.x;
+    const int HW = a.H * a.W;
+    const int e1 = a.ext ? a.ext[2 * b] : a.H, e2 = a.ext ? a.ext[2 * b + 1] : a.W;
+    float so = 0.f, sm = 0.f, ss = 0.f, sn = 0.f;
+    const long long base = (long long)b * a.C * HW;
+    for (int i = threadIdx.x; i < a.C * HW; i += HB) {
+        const int p = i % HW, y = p / a.W, x = p - y * a.W;
+        if (y >= e1 || x >= e2) continue;
+        const float c = a.clean[base + i];
+        if (a.out) { const float d = a.out[base + i] - c; so += d * d; }
+        if (a.mu) { const float d = a.mu[base + i] - c; sm += d * d; }
     }
-    float t = block_sum(acc, sh);
-    if (threadIdx.x == 0) a.dst[b] = t / (float)a.n;
+    if (a.model_std)
+        for (int i = threadIdx.x; i < HW; i += HB) ss += a.model_std[(long long)b * HW + i];
+    const bool npix = a.noise_std && a.noise_n == a.B * HW;
+    if (npix)
+        for (int i = threadIdx.x; i < HW; i += HB) sn += a.noise_std[(long long)b * HW + i];
+    so = block_sum(so, sh); __syncthreads();
+    sm = block_sum(sm, sh); __syncthreads();
+    ss = block_sum(ss, sh); __syncthreads();
+    sn = block_sum(sn, sh);
+    if (threadIdx.x == 0) {
+        const float cnt = (float)a.C * (float)e1 * (float)e2;
+        float* q = a.per + 8 * b;
+        q[0] = a.loss ? a.loss[b] : 0.f;
+        q[1] = a.out ? -10.f * log10f(so / cnt) : 0.f;
+        q[2] = a.mu ? -10.f * log10f(sm / cnt) : 0.f;
+        q[3] = !a.noise_std ? 0.f : 255.f * (npix ? sn / (float)HW : a.noise_std[a.noise_n == a.B ? b : 0]);
+        q[4] = a.model_std ? 255.f * ss / (float)HW : 0.f;
+        __threadfence();
+        const unsigned t = atomicAdd(reinterpret_cast<unsigned*>(a.acc + 15), 1u);
+        last = t == (unsigned)a.B - 1;
+    }
+    __syncthreads();
+    if (last && threadIdx.x < 5) {
+        __threadfence();
+        const int k = threadIdx.x;
+        const bool on = k == 0 ? a.loss != nullptr : k == 1 ? a.out != nullptr : k == 2 ? a.mu != nullptr : k == 3 ? a.noise_std != nullptr : a.model_std != nullptr;
+        if (on) {
+            const bool once = k == 3 && a.noise_n == 1;             // one noise level for the whole batch: a single sample of the metric
+            float sum = 0.f;
+            const int nb = once ? 1 : a.B;
+            for (int j = 0; j < nb; ++j) sum += __hip_atomic_load(a.per + 8 * j + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            a.acc[2 * k] += sum;
+            a.acc[2 * k + 1] += (float)nb;
+        }
+        if (k == 0) *reinterpret_cast<unsigned*>(a.acc + 15) = 0u;
+    }
 }
-int launch_sqerr(const ssdn_sqerr_args* a, hipStream_t s) {
-    hipLaunchKernelGGL(k_sqerr, dim3(a->B), dim3(HB), 0, s, *a);
+int launch_metrics(const ssdn_metrics_args* a, hipStream_t s) {
+    if (!a->clean || !a->per || !a->acc) return ssdn_set_error("metrics: clean, per and acc must be given");
+    if (a->B < 1 || a->C < 1 || a->H < 1 || a->W < 1) return ssdn_set_error("metrics: bad shape");
+    if (a->noise_std && a->noise_n != 1 && a->noise_n != a->B && a->noise_n != a->B * a->H * a->W) return ssdn_set_error("metrics: noise_n must be 1, B or B*H*W");
+    hipLaunchKernelGGL(k_metrics, dim3(a->B), dim3(HB), 0, s, *a);
     return 0;
 }

@@ -37,6 +37,37 @@ class CleanPatches(Dataset):
         img = self.noisy.child[index][0]
         return (img * 255.0).round().clamp_(0, 255).to(torch.uint8), index
 
+    def __getitems__(self, indexes):
+        """One worker call per MINIBATCH (torch's fetcher uses it when present).  An HDF5 child under the training crop reads only
+        the crop windows (HDF5Dataset.patches_u8: tens of thousands of patches/s per worker instead of 450 through PIL + float).
+        Returns the per-sample list any collate function expects -- the samples are views of ONE uint8 [B, C, P, P] array, which
+        `CleanPatches.collate` hands over as it is."""
+        from ssdn.datasets.transforms import RandomCrop
+        child = self.noisy.child
+        tf = getattr(child, "transform", None)
+        if hasattr(child, "patches_u8") and isinstance(tf, RandomCrop) and tf.pad_if_needed and tf.padding_mode == "reflect" and \
+                getattr(child, "output_format", None) is not None:
+            base = torch.from_numpy(child.patches_u8(list(indexes), tf.size))
+            out = _PreBatched((base[k], int(i)) for k, i in enumerate(indexes))
+            out.base, out.indexes = base, torch.as_tensor(list(indexes), dtype=torch.int64)
+            return out
+        return [self[i] for i in indexes]
+
+    @staticmethod
+    def collate(batch):
+        """collate_fn of the training DataLoader: a minibatch `__getitems__` built in one piece is passed through, anything else
+        is stacked the default way"""
+        if isinstance(batch, _PreBatched):
+            return batch.base, batch.indexes
+        from torch.utils.data import default_collate
+        return default_collate(batch)
+
+
+class _PreBatched(list):
+    """list of (patch, index) samples that are views of `base` (uint8 [B, C, P, P]); `indexes` int64 [B]"""
+    base = None
+    indexes = None
+
 
 class _Uploaded:
     """a minibatch on its way to the device (DevicePatchStream.upload): device tensor, completion event, the pinned source (kept

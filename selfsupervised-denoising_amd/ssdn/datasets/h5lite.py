@@ -176,6 +176,8 @@ class ImageFile:
 
     def __init__(self, path: str):
         self.fh = _File(path)
+        self.path = path
+        self._map, self._map_pid = None, -1
         links = _group_links(self.fh, _superblock(self.fh))
         for name in ("images", "shapes"):
             if name not in links:
@@ -227,6 +229,29 @@ class ImageFile:
     def image(self, i: int) -> np.ndarray:
         """uint8 array with the stored shape (3, h, w)"""
         return self.image_bytes(i).reshape(tuple(int(v) for v in self.shapes[i]))
+
+    def image_location(self, i: int) -> Tuple[int, int]:
+        """(absolute file offset, byte length) of image i's raw CHW payload"""
+        loc = self._locs.get(i) if hasattr(self, "_locs") else None
+        if loc is None:
+            if not hasattr(self, "_locs"):
+                self._locs = {}
+            ln, haddr, hidx = struct.unpack("<IQI", self.fh.read(self.iaddr + 16 * i, 16))
+            off, osz = self._heap_object(haddr, hidx)
+            if osz < ln:
+                raise H5LiteError("heap object shorter than the sequence length")
+            loc = self._locs[i] = (self.fh.base + off, ln)
+        return loc
+
+    def view(self, i: int) -> np.ndarray:
+        """Image i as a read-only (3, h, w) VIEW of the memory-mapped file: slicing a window out of it touches only the pages
+        of that window (the training loader crops 64x64 patches out of ~0.5 MB images).  The mapping is per process and
+        read-only: nothing a forked DataLoader worker could race on."""
+        if getattr(self, "_map", None) is None or self._map_pid != os.getpid():
+            self._map = np.memmap(self.path, dtype=np.uint8, mode="r")
+            self._map_pid = os.getpid()
+        off, ln = self.image_location(i)
+        return self._map[off:off + ln].reshape(tuple(int(v) for v in self.shapes[i]))
 
     def close(self):
         self.fh.close()

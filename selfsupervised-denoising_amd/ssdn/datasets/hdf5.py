@@ -55,6 +55,37 @@ class HDF5Dataset(Dataset):
             img = img.permute(0, 2, 1)
         return img, index
 
+    # ---- crop at read (the training loader's fast path, ssdn.datasets.device_stream.CleanPatches) -------------------------------
+    def patches_u8(self, indexes, size: int) -> np.ndarray:
+        """uint8 [len(indexes), channels, size, size]: one uniformly placed size x size crop of every listed image, exactly what
+        `self[i]` yields under `RandomCrop(size, pad_if_needed=True, padding_mode="reflect")` as bytes -- same value mapping
+        (PIL's RGB -> L weights for one channel), same swapped H/W (out[c, i, j] = stored[c, top + j, left + i]) -- but only the
+        crop window is read (memory-mapped file), no PIL image, no float round trip, one call per MINIBATCH.  Crop positions come
+        from torch's generator, like RandomCrop's (parity of positions is distributional, transforms.py).  Images smaller than the
+        patch, or a non-h5lite backend, take the per-item path."""
+        h = self._open()
+        n = len(indexes)
+        out = np.empty((n, self.channels, size, size), dtype=np.uint8)
+        u = torch.rand(2 * n).numpy()
+        fast = hasattr(h, "view")
+        for k, idx in enumerate(indexes):
+            c, ih, iw = (int(v) for v in h.shapes[idx])
+            if not fast or ih < size or iw < size or c not in (1, 3):
+                img = self[idx][0]                                   # (reflect padding etc.: the generic path; needs a RandomCrop transform)
+                out[k] = (img * 255.0).round().clamp_(0, 255).to(torch.uint8).numpy()
+                continue
+            top = min(int(u[2 * k] * (ih - size + 1)), ih - size)
+            left = min(int(u[2 * k + 1] * (iw - size + 1)), iw - size)
+            win = h.view(idx)[:, top:top + size, left:left + size]      # (c, y, x) view of the mapped file
+            if c == self.channels:
+                out[k] = win.transpose(0, 2, 1)
+            elif self.channels == 1:                                    # PIL "L": (R * 19595 + G * 38470 + B * 7471 + 0x8000) >> 16
+                w32 = win.astype(np.uint32)
+                out[k, 0] = ((w32[0] * 19595 + w32[1] * 38470 + w32[2] * 7471 + 0x8000) >> 16).astype(np.uint8).T
+            else:                                                       # one stored channel, three wanted: replicated
+                out[k] = np.broadcast_to(win[0].T, (3, size, size))
+        return out
+
     def image_size(self, index: int, ignore_transform: bool = False) -> torch.Tensor:
         if self.transform is not None and not ignore_transform:
             return torch.tensor(self[index][0].shape)

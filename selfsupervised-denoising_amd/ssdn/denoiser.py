@@ -242,6 +242,7 @@ class Denoiser(nn.Module):
         else:
             eng.net_forward_only()
         self._last_engine = eng
+        self._has_loss_last = have_loss
         if train:
             self._last_train_engine = eng
         own = (lambda t: t.clone()) if clone else (lambda t: t)
@@ -310,13 +311,63 @@ class Denoiser(nn.Module):
         net = self._models[Denoiser.MODEL]
         return dp.GradExchange(world, dp.bucket_ranges(net.layers, self._n_main, self.flat.numel()), self.device)
 
-    def train_step(self, data: List, lr: float, exchange=None) -> Dict:
+    # ---- H11: per-step metrics on the device ---------------------------------------------------------------------------
+    METRIC_NAMES = ("loss", "psnr_out", "psnr_mu_out", PipelineOutput.NOISE_STD_DEV.value, PipelineOutput.MODEL_STD_DEV.value)
+
+    def _metrics_acc(self, kind: str) -> Tensor:
+        accs = self.__dict__.setdefault("_macc", {})
+        if kind not in accs:
+            accs[kind] = torch.zeros(16, dtype=torch.float32, device=self.device)
+        return accs[kind]
+
+    def accumulate_metrics(self, data: List, kind: str = "train", with_loss: bool = True, per_sample: bool = False):
+        """Add the metrics of the LAST `run_pipeline` / `train_step` batch (`data` = its inputs) to the device-resident accumulator
+        `kind` with one kernel launch (SSDN_OP_METRICS: loss, PSNR of IMG_DENOISED and IMG_MU against the clean image over each
+        sample's un-padded extent, noise / model std-dev x 255 -- what the reference trainer accumulates with ~20 ATen launches per
+        step, train.py:205-218, utils/data.py:94-105).  Nothing is copied to the host; `read_metrics` does that when the trainer
+        prints.  per_sample=True returns {"psnr_out": [B], "psnr_mu_out": [B]} of this batch (host tensors: synchronises)."""
+        eng = self._last_engine
+        if eng is None:
+            raise RuntimeError("accumulate_metrics() needs a preceding run_pipeline()")
+        meta = data[NoisyDataset.METADATA]
+        MD = NoisyDataset.Metadata
+        clean = meta[MD.CLEAN]
+        B = clean.shape[0]
+        if clean.device != self.device or clean.dtype != torch.float32 or not clean.is_contiguous():
+            clean = clean.to(self.device, torch.float32, non_blocking=True).contiguous()
+        ext = None
+        shp = meta.get(MD.IMAGE_SHAPE)
+        if shp is not None:
+            shp = torch.as_tensor(shp).reshape(B, -1)[:, -2:].to(torch.int32)
+            if bool((shp != torch.tensor(list(clean.shape[-2:]), dtype=torch.int32)).any()):
+                ext = shp.to(self.device, non_blocking=True).contiguous()
+        eng.accumulate_metrics(self._metrics_acc(kind), clean, ext, with_loss=with_loss and self._has_loss_last)
+        self._metrics_keep = (clean, ext)               # alive until the launch has run
+        if per_sample:
+            per = eng.metrics_per.cpu()
+            res = {"psnr_out": per[:, 1].clone()}
+            if self._pipeline == Pipeline.SSDN:
+                res["psnr_mu_out"] = per[:, 2].clone()
+            return res
+        return None
+
+    def read_metrics(self, kind: str = "train", reset: bool = True) -> Dict[str, Tuple[float, int]]:
+        """{metric name: (sum over samples, sample count)} accumulated since the last reset -- ONE 64-byte copy to the host."""
+        acc = self._metrics_acc(kind)
+        v = acc.cpu().tolist()
+        if reset:
+            acc.zero_()
+        return {name: (v[2 * k], int(round(v[2 * k + 1]))) for k, name in enumerate(self.METRIC_NAMES) if v[2 * k + 1] > 0}
+
+    def train_step(self, data: List, lr: float, exchange=None, metrics: bool = False) -> Dict:
         """One whole optimisation step on this GPU: forward + loss + backward + Adam.  exchange: `gradient_exchange(world)`
         for data parallelism -- the per-bucket all-reduces are issued behind events recorded inside the backward list, so
         they overlap the rest of the backward pass; Adam waits for them and folds in 1 / world."""
         from ssdn.hip import dp
         out = self._run(data, clone=False, bridge=False)
         eng = self._last_train_engine
+        if metrics:                         # (reads the forward pass's outputs: enqueued in front of the backward pass)
+            self.accumulate_metrics(data, "train")
         from ssdn.hip import engine as _engine
         scale = dp.exchange_step(lambda ex: eng.backward(exchange=ex, defer_tail=ex is None and _engine.DEFER_TAIL), self.flat_grad, exchange)
         self.optimizer_step(lr, scale)

@@ -439,6 +439,10 @@ class DenoiserEngine:
         self.noise_std = torch.zeros((B, H, W) if self.style == "poisson" else (B,), **f32)
         self.zero_buf = torch.zeros((8,), dtype=torch.int32, device=device)   # unused gmax sink for eval
         self._adam_args = None
+        # H11: loss / PSNR / std-dev sums of a step go into a device-resident accumulator (SSDN_OP_METRICS); `per` holds the last
+        # batch's per-sample values (the evaluator's per-image PSNR)
+        self.metrics_per = torch.zeros((B, 8), **f32)
+        self._metrics_args = None
         self.ops_loss = OpList(self._loss_ops(want_grad=train))
         opt_recs = self._opt_ops() if train else None          # (both lists share the argument structs adam() updates)
         self.ops_opt = OpList(opt_recs) if train else None
@@ -500,6 +504,31 @@ class DenoiserEngine:
             self._adam_args.append(adam(n_main, n_tot))
             recs += [("adam", self._adam_args[1])] + [self.sigma._mat(op) for op in self.sigma.plan.pack]
         return recs
+
+    # ---- metrics (H11) -------------------------------------------------------------------------------------
+    def accumulate_metrics(self, acc: torch.Tensor, clean: torch.Tensor, ext: Optional[torch.Tensor] = None, with_loss: bool = True,
+                           stream=None):
+        """Enqueue ONE launch that adds this batch's loss / PSNR(out) / PSNR(mu) / noise std / model std sums into `acc` (fp32 [16] on
+        the device: sum, count per metric) -- the reference's per-step `Metric +=` lines (train.py:205-218).  clean: fp32 [B,C,H,W] on
+        the device; ext: int32 [B,2] valid extents of the two spatial axes (padded evaluation images) or None."""
+        a = self._metrics_args
+        if a is None:
+            a = self._metrics_args = L.MetricsArgs()
+            a.B, a.C, a.H, a.W = self.B, self.C, self.H, self.W
+            a.per = _ptr(self.metrics_per)
+            if self.pipeline == "ssdn":
+                a.out, a.mu, a.model_std, a.noise_std = _ptr(self.pme), _ptr(self.mu), _ptr(self.model_std), _ptr(self.noise_std)
+                # (gauss: one value per sample -- one for the whole batch when sigma is a learnt constant; poisson: per pixel)
+                a.noise_n = self.noise_std.numel() if self.style == "poisson" else (1 if self.mode == "const" else self.B)
+            else:
+                a.out = _ptr(self.main.tensor("out32"))
+            self._metrics_ops = OpList([("metrics", a)])
+        if clean.dtype != torch.float32 or not clean.is_contiguous() or tuple(clean.shape) != (self.B, self.C, self.H, self.W):
+            raise L.SsdnHipError("metrics: clean must be a contiguous fp32 [B,C,H,W] device tensor of the engine's shape")
+        a.clean, a.acc = _ptr(clean), _ptr(acc)
+        a.loss = _ptr(self.loss) if with_loss else None
+        a.ext = _ptr(ext) if ext is not None else None
+        self._metrics_ops.run(current_stream() if stream is None else stream)
 
     # ---- execution -----------------------------------------------------------------------------------------
     def repack(self, stream=None):

@@ -15,7 +15,7 @@ MAX_TAPS = 9
 # op type codes (enum ssdn_op_type)
 OP = dict(pack_input=1, conv=2, pool_fwd=3, pool_bwd=4, upsum_bwd=5, unrot_fwd=6, unrot_bwd=7, wgrad=8, wreduce=9,
           wpack=10, grad_pack=11, head_ssdn=12, head_final=13, spatial_mean=14, mse=15, mask_mse=16, adam=17,
-          sqerr=18, zero=19, event_record=20, noise=21)
+          metrics=18, zero=19, event_record=20, noise=21)
 
 i32, f32, vp = C.c_int32, C.c_float, C.c_void_p
 
@@ -102,8 +102,9 @@ class AdamArgs(C.Structure):
                 ("eps", f32), ("bc1", f32), ("bc2", f32), ("gscale", f32)]
 
 
-class SqerrArgs(C.Structure):
-    _fields_ = [("a", vp), ("b", vp), ("dst", vp), ("B", i32), ("n", i32)]
+class MetricsArgs(C.Structure):
+    _fields_ = [("out", vp), ("mu", vp), ("clean", vp), ("loss", vp), ("model_std", vp), ("noise_std", vp), ("ext", vp),
+                ("B", i32), ("C", i32), ("H", i32), ("W", i32), ("noise_n", i32), ("per", vp), ("acc", vp)]
 
 
 class ZeroArgs(C.Structure):
@@ -123,10 +124,10 @@ class NoiseArgs(C.Structure):
 ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, pool_bwd=PoolArgs, upsum_bwd=UpsumArgs,
                  unrot_fwd=UnrotArgs, unrot_bwd=UnrotArgs, wgrad=WgradArgs, wreduce=WreduceArgs, wpack=WpackArgs,
                  grad_pack=GradPackArgs, head_ssdn=HeadArgs, head_final=HeadFinalArgs, spatial_mean=SpatialMeanArgs,
-                 mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, sqerr=SqerrArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
+                 mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, metrics=MetricsArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 8      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 9      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",

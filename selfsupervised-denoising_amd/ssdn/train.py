@@ -42,6 +42,7 @@ from ssdn.params import ConfigValue, DatasetType, HistoryValue, Pipeline, Pipeli
 from ssdn.utils import Metric, MetricDict, TrackedTime, separator
 
 logger = logging.getLogger("ssdn.train")
+_PSNR_CACHE = "_psnr_per_sample"          # key of the per-sample PSNR values the device metric kernel produced for an output dict
 
 
 class _RankShard(torch.utils.data.Sampler):
@@ -179,6 +180,7 @@ class DenoiserTrainer:
             if iteration % self.cfg[ConfigValue.EVAL_INTERVAL] == 0 and self.testloader is not None:
                 self._evaluate(self.testloader, output_callback=self.validation_output_callback(0))
             if iteration % self.cfg[ConfigValue.PRINT_INTERVAL] == 0:
+                self._flush_device_metrics()
                 history[HistoryValue.TIMINGS]["total"].update()
                 last_print = history[HistoryValue.TIMINGS]["last_print"]
                 last_print.update()
@@ -195,15 +197,19 @@ class DenoiserTrainer:
             data = next(data_itr)
             image_count = data[NoisyDataset.INPUT].shape[0]
             denoiser.train()
-            outputs = denoiser.train_step(data, self.learning_rate, self._exchange)
-            with torch.no_grad():
-                train_history["n"] += image_count
-                train_history["loss"] += outputs[PipelineOutput.LOSS]
-                for key, name in self.img_outputs(prefix="psnr").items():
-                    train_history[name] += self.calculate_psnr(outputs, key, False)
-                for key in (PipelineOutput.NOISE_STD_DEV, PipelineOutput.MODEL_STD_DEV):
-                    if key in outputs:
-                        train_history[key.value] += outputs[key] * 255
+            # H11: on a GPU the step's metric sums stay on the device (one kernel inside train_step, SSDN_OP_METRICS) and come to the
+            # host when the trainer prints; the reference's per-step tensor arithmetic (train.py:205-218) is the CPU path
+            on_device = getattr(denoiser, "device", torch.device("cpu")).type == "cuda" and torch.is_tensor(data[NoisyDataset.METADATA].get(MD.CLEAN))
+            outputs = denoiser.train_step(data, self.learning_rate, self._exchange, **({"metrics": True} if on_device else {}))
+            train_history["n"] += image_count
+            if not on_device:
+                with torch.no_grad():
+                    train_history["loss"] += outputs[PipelineOutput.LOSS]
+                    for key, name in self.img_outputs(prefix="psnr").items():
+                        train_history[name] += self.calculate_psnr(outputs, key, False)
+                    for key in (PipelineOutput.NOISE_STD_DEV, PipelineOutput.MODEL_STD_DEV):
+                        if key in outputs:
+                            train_history[key.value] += outputs[key] * 255
             # images consumed by the whole job: rows x world for a sharded minibatch, the true count for the un-sharded tail
             self.state[StateValue.ITERATION] += self._shard.counts.popleft() if self._shard is not None else image_count
         logger.info(separator())
@@ -212,6 +218,18 @@ class DenoiserTrainer:
         if self.rank == 0:
             self.snapshot()
             self.snapshot(output_name="final-{}.wt".format(self.denoiser.config_name()), subdir="", model_only=True)
+
+    def _flush_device_metrics(self):
+        """Bring the sums the training steps left on the device (Denoiser.accumulate_metrics) into the history's Metric objects:
+        one 64-byte read per PRINT_INTERVAL instead of ~20 launches and a `Metric +=` per step."""
+        d = self._denoiser
+        if d is None or getattr(d, "device", torch.device("cpu")).type != "cuda" or not hasattr(d, "read_metrics"):
+            return
+        train_history = self.state[StateValue.HISTORY][HistoryValue.TRAIN]
+        for name, (total, count) in d.read_metrics("train", reset=True).items():
+            m = train_history[name]
+            m.total = total if m.total is None else m.total + total
+            m.n += count
 
     def evaluate(self, dataloader: DataLoader, output_callback: Callable = None):
         self.reset_metrics(train=False)
@@ -226,6 +244,10 @@ class DenoiserTrainer:
                 image_count = data[NoisyDataset.INPUT].shape[0]
                 outputs = self.denoiser.run_pipeline(data)
                 eval_history["n"] += image_count
+                if getattr(self.denoiser, "device", torch.device("cpu")).type == "cuda":
+                    # per-image PSNR over the un-padded extent from ONE kernel (the values are needed on the host: psnrs.csv)
+                    per = self.denoiser.accumulate_metrics(data, "eval", with_loss=False, per_sample=True)
+                    outputs[_PSNR_CACHE] = {key: per[name] for key, name in self.img_outputs(prefix="psnr").items() if name in per}
                 for key, name in self.img_outputs(prefix="psnr").items():
                     eval_history[name] += self.calculate_psnr(outputs, key, unpad=True)
                 if output_callback:
@@ -269,6 +291,8 @@ class DenoiserTrainer:
 
     def snapshot(self, output_name: str = None, subdir: str = None, model_only: bool = False):
         """`models/model_XXXXXXXX.wt` (Denoiser.state_dict()) or `training/model_XXXXXXXX.training` (everything to resume)."""
+        if not model_only:
+            self._flush_device_metrics()         # (the history in a `.training` file holds everything trained on so far)
         if subdir is None:
             subdir = "models" if model_only else "training"
         out_dir = os.path.join(self.run_dir_path, subdir)
@@ -330,6 +354,9 @@ class DenoiserTrainer:
 
     @staticmethod
     def calculate_psnr(outputs: Dict, output: PipelineOutput, unpad: bool = True) -> Tensor:
+        cached = outputs.get(_PSNR_CACHE)
+        if cached is not None and output in cached and unpad:
+            return cached[output]
         metadata = outputs[PipelineOutput.INPUTS][NoisyDataset.METADATA]
         clean = metadata[NoisyDataset.Metadata.CLEAN]
         img = outputs[output]
@@ -447,6 +474,8 @@ class DenoiserTrainer:
                          (torch.cuda.is_available() and not os.environ.get("SSDN_HOST_DATA"))) and \
             cfg[ConfigValue.TRAIN_PATCH_SIZE] % NoiseNetwork.input_wh_mul() == 0
         source = CleanPatches(dataset) if device_stream else dataset
+        if device_stream:
+            kw["collate_fn"] = CleanPatches.collate          # (the workers deliver whole minibatches: CleanPatches.__getitems__)
         if self.world > 1:
             _ = iter(sampler)                        # materialise the order under the common seed, then reuse it
             sampler.for_next_iter(sampler.last_iter())

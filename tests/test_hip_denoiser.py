@@ -383,3 +383,40 @@ def test_fused_adam_repack_is_bit_identical_to_adam_then_wpack(alg, style, mode)
     for nm, x, y in zip(names, fused, plain):
         assert torch.equal(x.view(torch.uint8) if x.dtype not in (torch.float32,) else x, y.view(torch.uint8) if y.dtype not in (torch.float32,) else y), nm
     assert not torch.equal(fused[0], start[0])                    # (the step did move the parameters)
+
+
+@pytest.mark.parametrize("alg,style,mode", [("ssdn", "gauss25", "known"), ("ssdn", "poisson30", "const"), ("n2c", "gauss25", "known")])
+def test_device_metric_accumulators_equal_the_host_formulas(alg, style, mode):
+    """H11: `train_step(metrics=True)` leaves the step's loss / PSNR / std-dev sums in a device accumulator (one SSDN_OP_METRICS launch
+    per step); after three steps `read_metrics()` must equal what the reference trainer's per-step lines accumulate on the host
+    (train.py:205-218: `Metric += value` with utils/data.py:94-105 and utils/utils.py Metric.add) to 1e-5 relative."""
+    import ssdn
+    from ssdn.datasets import NoisyDataset
+    from ssdn.params import PipelineOutput
+    from ssdn.utils import Metric
+    MD = NoisyDataset.Metadata
+    d = make_denoiser(alg, style, mode, 3)
+    d.train()
+    B, P = 4, 32
+    host = {}
+    for step in range(3):
+        clean = R.hash_tensor((B, 3, P, P), 500 + step, 0, 1)
+        noisy = torch.clamp(clean + R.hash_tensor((B, 3, P, P), 600 + step, -1, 1) * 0.17, 0, 1)
+        data = [noisy.cuda(), clean.cuda(), {MD.INPUT_NOISE_VALUES: torch.full((B, 1, 1, 1), 25 / 255.0), MD.CLEAN: clean.cuda(),
+                                             MD.IMAGE_SHAPE: torch.tensor([3, P, P]).repeat(B, 1)}]
+        out = d.train_step(data, 3e-4, None, metrics=True)
+        torch.cuda.synchronize()
+        host.setdefault("loss", Metric()).add(out[PipelineOutput.LOSS].detach().cpu().clone())
+        host.setdefault("psnr_out", Metric()).add(ssdn.utils.calculate_psnr(out[PipelineOutput.IMG_DENOISED].detach().cpu(), clean))
+        if PipelineOutput.IMG_MU in out:
+            host.setdefault("psnr_mu_out", Metric()).add(ssdn.utils.calculate_psnr(out[PipelineOutput.IMG_MU].detach().cpu(), clean))
+        for key in (PipelineOutput.NOISE_STD_DEV, PipelineOutput.MODEL_STD_DEV):
+            if key in out:
+                host.setdefault(key.value, Metric()).add(out[key].detach().cpu().clone() * 255)
+    got = d.read_metrics("train", reset=True)
+    assert set(got) == set(host), (sorted(got), sorted(host))
+    for name, m in host.items():
+        total, count = got[name]
+        assert count == m.n, (name, count, m.n)
+        assert float(total) == pytest.approx(float(torch.as_tensor(m.total).sum()), rel=1e-5, abs=1e-6), name
+    assert d.read_metrics("train") == {}                       # reset

@@ -151,12 +151,37 @@ def test_fused_adam_vs_oracle():
     np.testing.assert_allclose(dv.cpu().numpy(), v.numpy(), rtol=1e-5, atol=1e-12)
 
 
-def test_sqerr_psnr(golden_dir):
+def test_metrics_kernel_vs_reference_psnr_and_host_formulas(golden_dir):
+    """SSDN_OP_METRICS (H11): per-sample PSNR against the reference-generated golden values, and the accumulated sums / counts of two
+    launches against the host formulas the reference trainer applies every step (train.py:205-218 with Metric.add)."""
     from ssdn.hip import lib as L
     a = R.hash_tensor((3, 3, 16, 16), 71, 0, 1)
     b = torch.clamp(a + R.hash_tensor((3, 3, 16, 16), 72, -0.1, 0.1), 0, 1)
-    dst = torch.zeros(3, device=dev())
-    da, db = a.to(dev()), b.to(dev())
-    run_one("sqerr", L.SqerrArgs(P(da), P(db), P(dst), 3, 3 * 16 * 16))
-    psnr = -10 * np.log10(dst.cpu().numpy())
-    np.testing.assert_allclose(psnr, np.load(os.path.join(golden_dir, "g_psnr.npz"))["psnr"], rtol=1e-5)
+    mu = torch.clamp(a + R.hash_tensor((3, 3, 16, 16), 73, -0.2, 0.2), 0, 1)
+    loss = R.hash_tensor((3,), 74, -1, 1)
+    mstd = R.hash_tensor((3, 16, 16), 75, 0, 0.1)
+    nstd = R.hash_tensor((3,), 76, 0.05, 0.2)
+    d = lambda t: t.to(dev()).contiguous()   # noqa: E731
+    da, db, dmu, dl, dm, dn = d(a), d(b), d(mu), d(loss), d(mstd), d(nstd)
+    per = torch.zeros(3, 8, device=dev())
+    acc = torch.zeros(16, device=dev())
+    args = L.MetricsArgs(P(db), P(dmu), P(da), P(dl), P(dm), P(dn), None, 3, 3, 16, 16, 3, P(per), P(acc))
+    run_one("metrics", args)
+    np.testing.assert_allclose(per[:, 1].cpu().numpy(), np.load(os.path.join(golden_dir, "g_psnr.npz"))["psnr"], rtol=1e-5)
+    run_one("metrics", args)                       # accumulates
+    psnr = lambda x: (-10 * torch.log10(((x - a) ** 2).reshape(3, -1).mean(1)))   # noqa: E731
+    want = [2 * float(loss.sum()), 2 * float(psnr(b).sum()), 2 * float(psnr(mu).sum()), 2 * float((nstd * 255).sum()),
+            2 * float((mstd * 255).reshape(3, -1).mean(1).sum())]
+    got = acc.cpu().numpy()
+    np.testing.assert_allclose(got[0:10:2], want, rtol=2e-5)
+    assert list(got[1:10:2]) == [6.0] * 5 and got[15] == 0
+    # padded evaluation batch: PSNR over each sample's valid extent only; one noise level for the whole batch counts once
+    ext = torch.tensor([[16, 16], [10, 12], [5, 16]], dtype=torch.int32, device=dev())
+    acc.zero_()
+    args2 = L.MetricsArgs(P(db), None, P(da), None, None, P(dn), P(ext), 3, 3, 16, 16, 1, P(per), P(acc))
+    run_one("metrics", args2)
+    want_p = [float(-10 * torch.log10(((b[i, :, :e1, :e2] - a[i, :, :e1, :e2]) ** 2).mean())) for i, (e1, e2) in enumerate([(16, 16), (10, 12), (5, 16)])]
+    np.testing.assert_allclose(per[:, 1].cpu().numpy(), want_p, rtol=2e-5)
+    got = acc.cpu().numpy()
+    assert got[1] == 0 and got[3] == 3 and got[5] == 0 and got[7] == 1 and got[9] == 0
+    np.testing.assert_allclose(got[6], float(nstd[0]) * 255, rtol=1e-6)
