@@ -31,7 +31,10 @@ def main():
         from ssdn.datasets import NoisyDataset
         from ssdn.params import ConfigValue, NoiseAlgorithm, NoiseValue, PipelineOutput
         MD = NoisyDataset.Metadata
+        only = sys.argv[1:]
         for tag, (alg, style, mode, B, P) in F.CASES.items():
+            if only and tag not in only:
+                continue
             cfg = ssdn.cfg.base()
             cfg[ConfigValue.ALGORITHM] = NoiseAlgorithm(alg)
             cfg[ConfigValue.NOISE_STYLE] = style
@@ -39,7 +42,7 @@ def main():
             cfg[ConfigValue.IMAGE_CHANNELS] = 3
             ssdn.cfg.infer(cfg, model_only=True)
             d = Denoiser(cfg, device="cpu")
-            d._models[Denoiser.MODEL].load_state_dict(R.reference_state_dict(R.make_params(3, 9, True, seed=5)))
+            d._models[Denoiser.MODEL].load_state_dict(R.reference_state_dict(F.params(tag)))
             clean, noisy, npar = F.inputs(tag)
             meta = {MD.INPUT_NOISE_VALUES: npar, MD.IMAGE_SHAPE: None, MD.CLEAN: clean}
             o = d.run_pipeline([noisy, clean, meta])

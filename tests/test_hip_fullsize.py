@@ -106,19 +106,28 @@ def test_config5_shard_ssdn_poisson_sigma_const_b16_128():
     _run_config("ssdn", "poisson30", "const", 16, 128, loss_rtol=2e-2, min_cos=0.98, min_agree=0.94)
 
 
-# Bounds = 2-4x what this test measured on MI355X (profiles/r03_parity_fullsize.txt is its own output).  Config 2 (the bench
-# workload) is well conditioned: loss 4.0e-4, PSNR 0.002 dB, gradient norms 5.6e-3, per-layer cosine >= 0.99994.  Config 5
-# (Poisson noise with an estimated scale at random-init weights) is not -- the Poisson variance mu / lambda sits at its clamp for
-# many pixels, and two kernel selections of THIS library whose activations differ by one fp16 ulp differ by 5e-3 in the loss
-# (tools/path_compare.py) -- hence its looser numbers: loss 4.8e-3, gradient norms 5.8e-2, worst layer cosine 0.988.
+# Bounds = 2-4x what this test measured on MI355X (profiles/r04_parity_fullsize.txt is its own output, from a PASSING run).  Config 2
+# (the bench workload) is well conditioned: loss 4e-4, PSNR 0.002 dB, gradient norms 6e-3, per-layer cosine >= 0.9999.  Config 5 at the
+# raw random initialisation is not: the network's output puts the model covariance's eigenvalues between 1e-5 and 5 against a
+# Poisson variance mu * est that sits at its clamp (1.9e-5) for most pixels, the posterior mean lies in [-5, 3] (PSNR 5 dB), and a
+# difference of 7.6e-4 (relative L2) in the network output -- fp16 activation storage -- moves it by > 1e-2 at 7 % of the pixels
+# (tools/pme_analysis.py, profiles/r04_pme_analysis_cfg5.txt).  For that case the test does not bound the raw difference of the
+# posterior mean; it DECOMPOSES it: (i) the head kernel against an fp64 evaluation of the reference's formula on the device's own
+# network output (`pme_kernel`), (ii) what is left of |device - fixture| after subtracting the fp64-propagated effect of the network
+# output difference, |f64(device net_out) - f64(oracle net_out)| (`pme_resid`), (iii) quantiles of the raw difference.  "cfg5b" is
+# config 5 with the last layer where training takes it (oracle/fullsize.py): conditioned, tight bounds.
 FULL_BOUNDS = {
     #        loss rel (vs reference)  PSNR dB   per-tensor |g| rel, first entries / |g|   per-layer / whole-gradient cosine (vs oracle)
-    "cfg2": dict(loss=1.5e-3, psnr=0.01, gnorm=2e-2, ghead=2e-2, layer_cos=0.9998, cos=0.99995),
-    "cfg5": dict(loss=1.2e-2, psnr=0.04, gnorm=0.12, ghead=0.15, layer_cos=0.975, cos=0.995),
+    "cfg2": dict(loss=1.5e-3, psnr=0.01, gnorm=2e-2, ghead=2e-2, layer_cos=0.9998, cos=0.99995,
+                 netout=2e-3, pme_kernel=5e-5, pme_resid=5e-4, pme_q50=6e-4, pme_q99=8e-3, pme_max=1.5e-2),
+    "cfg5": dict(loss=1.2e-2, psnr=0.04, gnorm=0.12, ghead=0.15, layer_cos=0.975, cos=0.995,
+                 netout=2e-3, pme_kernel=4e-3, pme_resid=3e-3, pme_q50=5e-5, pme_q99=6e-2, pme_max=None),
+    "cfg5b": dict(loss=1.5e-3, psnr=0.01, gnorm=2e-2, ghead=2e-2, layer_cos=0.9995, cos=0.99995,
+                  netout=1.5e-3, pme_kernel=5e-6, pme_resid=5e-4, pme_q50=3e-4, pme_q99=3e-3, pme_max=5e-3),
 }
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg5"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg5", "cfg5b"])
 def test_full_size_vs_live_reference_fixture(golden_dir, tag):
     """The sizes the bench and the config-5 shard RUN, against what the LIVE REFERENCE produced there (tests/golden/g_full_*.npz,
     oracle/gen_golden_fullsize.py: its own Denoiser.run_pipeline + mean(LOSS).backward() on oracle/fullsize.py's inputs): per-sample
@@ -136,7 +145,7 @@ def test_full_size_vs_live_reference_fixture(golden_dir, tag):
     bnd = FULL_BOUNDS[tag]
     d = make_denoiser(alg, style, mode, 3)
     d.train()
-    tr = R.CpuTrainer(alg, 3, style, mode, params=R.make_params(3, 9, True, seed=5))
+    tr = R.CpuTrainer(alg, 3, style, mode, params=F.params(tag))
     net = d.get_model(Denoiser.MODEL, False)
     nets = [(net, 0, tr.p)]
     d.flat.copy_(_flat_of(d, nets, tr))
@@ -156,6 +165,7 @@ def test_full_size_vs_live_reference_fixture(golden_dir, tag):
     probe_mu = float((mu[:, :, 3::16, 5::16] - torch.from_numpy(g["mu_probe"])).abs().max())
     dps = max(abs(float(R.psnr(pme[b:b + 1], clean[b:b + 1])) - float(g["psnr_out"][b])) for b in range(B))
     lines.append("  posterior mean probe: max abs diff %.3e; mu probe %.3e; per-image PSNR max |diff| %.4f dB (bound %.2f)" % (probe, probe_mu, dps, bnd["psnr"]))
+    no_dev = d._last_engine.main.tensor("out32").detach().cpu().clone()
     gd = d.flat_grad.cpu()
     worst_gn = worst_head = 0.0
     for name, (which, key) in param_name_map(g["names"]).items():
@@ -190,12 +200,31 @@ def test_full_size_vs_live_reference_fixture(golden_dir, tag):
     agree = float(((gd[:n] > 0) == (gr[:n] > 0)).float().mean())
     lines.append("  gradient vs fp32 oracle: whole cosine %.6f (bound %.4f), worst layer %s %.6f (bound %.4f), sign agreement %.4f" % (
         cos_all, bnd["cos"], worst_layer, worst_cos, bnd["layer_cos"], agree))
+    # ---- the posterior mean, decomposed ----
+    with torch.no_grad():
+        no_ref = r["net_out"].detach()
+        est64 = tr.est.detach().double() if tr.est is not None else None
+        f64 = lambda no: R.ssdn_head(no.double(), noisy.double(), npar.double(), style, mode, est64)["out"]   # noqa: E731
+        p64_dev, p64_ref = f64(no_dev), f64(no_ref)
+    pr = lambda t: t[:, :, 3::16, 5::16]   # noqa: E731
+    netout_rel = float((no_dev - no_ref).norm() / no_ref.norm())
+    pme_kernel = float((pr(pme).double() - pr(p64_dev)).abs().max())
+    raw = (pr(pme).double() - torch.from_numpy(g["out_probe"]).double()).abs()
+    resid = float((raw - (pr(p64_dev) - pr(p64_ref)).abs()).clamp(min=0).max())
+    q50, q99 = float(raw.median()), float(np.quantile(raw.numpy().ravel(), 0.99))
+    lines.append("  network output vs oracle: rel-L2 %.3e (bound %.1e); head kernel vs fp64 reference formula on the device's own net_out: max %.3e (bound %.1e)" % (
+        netout_rel, bnd["netout"], pme_kernel, bnd["pme_kernel"]))
+    lines.append("  posterior mean vs fixture at %d probes: median %.3e (bound %.1e), 99%% %.3e (bound %.1e), max %.3e (bound %s), %d probes > 1e-2; "
+                 "not explained by |f64(device net_out) - f64(oracle net_out)|: max %.3e (bound %.1e)" % (
+                     raw.numel(), q50, bnd["pme_q50"], q99, bnd["pme_q99"], float(raw.max()), bnd["pme_max"], int((raw > 1e-2).sum()), resid, bnd["pme_resid"]))
     os.makedirs(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"), exist_ok=True)
     with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "parity_fullsize_%s.txt" % tag), "w") as f:
         f.write("\n".join(lines) + "\n")
     print("\n".join(lines))
     assert loss_rel <= bnd["loss"] and dps <= bnd["psnr"] and worst_gn <= bnd["gnorm"] and worst_head <= bnd["ghead"], lines
     assert cos_all >= bnd["cos"] and worst_cos >= bnd["layer_cos"], lines
+    assert netout_rel <= bnd["netout"] and pme_kernel <= bnd["pme_kernel"] and resid <= bnd["pme_resid"], lines
+    assert q50 <= bnd["pme_q50"] and q99 <= bnd["pme_q99"] and (bnd["pme_max"] is None or float(raw.max()) <= bnd["pme_max"]), lines
 
 
 @pytest.mark.parametrize("P", [512, 768])

@@ -206,7 +206,7 @@ def test_param_grads(golden_dir, tag, alg, style, mode, ch):
         close(t.grad.reshape(-1)[:16], g["ghead/" + name], rtol=5e-3, atol=1e-6 + 1e-4 * gn)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg5"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg5", "cfg5b"])
 def test_full_size_oracle_vs_reference(golden_dir, tag):
     """The restatement at the sizes the bench and the config-5 shard RUN (batch 32 at 64x64; batch 16 at 128x128) against what the
     live reference produced there (oracle/gen_golden_fullsize.py): per-sample loss, per-tensor gradient norm and first entries,
@@ -214,7 +214,7 @@ def test_full_size_oracle_vs_reference(golden_dir, tag):
     import fullsize as F
     g = G(golden_dir, "g_full_" + tag)
     alg, style, mode, B, P = F.CASES[tag]
-    tr = R.CpuTrainer(alg, 3, style, mode, params=R.make_params(3, 9, True, seed=5))
+    tr = R.CpuTrainer(alg, 3, style, mode, params=F.params(tag))
     clean, noisy, npar = F.inputs(tag)
     torch.set_num_threads(min(8, os.cpu_count() or 1))
     r = tr.forward(noisy, clean, npar)
