@@ -184,6 +184,11 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     // list (another lane) waits for carries one as its stop event (SSDN_LAUNCH): the dependent lane waits without a hipEventRecord
     hipEvent_t cover[SSDN_NLANES] = {nullptr, nullptr, nullptr, nullptr};
     bool covered[SSDN_NLANES] = {false, false, false, false};
+    // ring position at which cover[s] was drawn: a cover stays live until the lane's next op or the final join, while every later
+    // draw advances the ring -- once SSDN_NEVENTS - 1 further events have been drawn the slot has been handed out again and the
+    // cover no longer stands for lane s: it is dropped, and whoever needs it records a fresh event
+    long long cover_at[SSDN_NLANES] = {0, 0, 0, 0};
+    auto cover_live = [&](int l) { return covered[l] && (!LS || (long long)LS->ev_next - cover_at[l] < SSDN_NEVENTS - 1); };
     bool has_side = false;
     static const bool no_stop = ssdn_tuning_env("SSDN_NO_STOP_EVENTS") != nullptr;      // A/B aid, read once
     for (int i = 0; i < n && !one_lane; ++i) has_side = has_side || ops[i].lane > 0;
@@ -199,7 +204,8 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             for (int l = 1; l < SSDN_NLANES; ++l) lane_s[l] = LS->side[l];
             for (int src = 0; src < SSDN_NLANES; ++src) {
                 if (!((g_lane_deps[lane] >> src) & 1) || !dirty[src][lane]) continue;
-                if (!covered[src]) {
+                if (!cover_live(src)) {
+                    cover_at[src] = LS->ev_next;
                     cover[src] = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
                     SSDN_CHECK_HIP(hipEventRecord(cover[src], lane_s[src]));
                     covered[src] = true;
@@ -215,10 +221,12 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
         // arm(j): the op (or merged run) being launched ends at list index j - 1; if the op at j runs on a lane that is ordered after
         // this one, the launch carries a stop event (attaching one to EVERY kernel costs each ~5 us of completion handling)
         bool armed = false;
+        long long armed_at = 0;
         auto arm = [&](int j) {
             if (!has_side || no_stop || j >= n) return;
             const int lj = one_lane ? 0 : ops[j].lane;
             if (lj == lane || lj < 0 || lj >= SSDN_NLANES || !((g_lane_deps[lj] >> lane) & 1)) return;
+            armed_at = LS->ev_next;
             g_ssdn_stop_event = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
             g_ssdn_stop_used = false;
             armed = true;
@@ -228,6 +236,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             if (!has_side || no_stop || lane == 0 || armed) return;
             for (; j < n; ++j)
                 if ((one_lane ? 0 : ops[j].lane) == lane) return;
+            armed_at = LS->ev_next;
             g_ssdn_stop_event = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
             g_ssdn_stop_used = false;
             armed = true;
@@ -347,7 +356,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             default: return ssdn_set_error("op %d: unknown type %d", i, ops[i].type);
         }
         if (armed) {
-            if (g_ssdn_stop_used && !rc) { cover[lane] = g_ssdn_stop_event; covered[lane] = true; }   // (the op's last launch carries it)
+            if (g_ssdn_stop_used && !rc) { cover[lane] = g_ssdn_stop_event; covered[lane] = true; cover_at[lane] = armed_at; }   // (the op's last launch carries it)
             g_ssdn_stop_event = nullptr;
         }
         if (rc) {
@@ -358,7 +367,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     }
     for (int l = 1; l < SSDN_NLANES; ++l) {   // join every side lane back into the caller's stream
         if (!used[l]) continue;
-        if (!covered[l]) {
+        if (!cover_live(l)) {
             cover[l] = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
             SSDN_CHECK_HIP(hipEventRecord(cover[l], lane_s[l]));
         }

@@ -97,6 +97,14 @@ extern thread_local bool g_ssdn_stop_used;
         } else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                \
     } while (0)
 
+// slot of the current device in the per-device tables of the launchers (hipFuncSetAttribute is per device)
+#define SSDN_MAX_DEVICES_ATTR 16
+static inline int ssdn_current_device_slot() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+    return dev % SSDN_MAX_DEVICES_ATTR;
+}
+
 // in-stream profiler (api.hip)
 void prof_begin(int kind, hipStream_t s);
 void prof_end(int kind, hipStream_t s, double flops, double bytes);

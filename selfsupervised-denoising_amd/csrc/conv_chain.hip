@@ -782,7 +782,8 @@ int launch_chain(const ssdn_op* ops, int n, bool any_lane, hipStream_t s) {
     ChainHit h;
     if (chain_lookup(ops, n, any_lane, &h)) return -1;
     if (h.len != n) return ssdn_set_error("conv chain: the run is not a chain of %d ops", n);
-    static bool attr_set = false;
+    static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
+    bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_chain<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv_chain<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

@@ -577,7 +577,8 @@ int conv_dma_lds_bytes(int mt) { return 2 * CD_TBYTES + 2 * mt * 32 * 96; }
 
 template <int MT, bool BF, int EPI>
 static int cd_launch(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
-    static bool attr_set = false;
+    static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
+    bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_cdma<MT, BF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;

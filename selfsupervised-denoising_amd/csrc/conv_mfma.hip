@@ -846,7 +846,8 @@ template <int MT, bool BF, int KS, int CONV_THREADS>
 static int conv_launch_mt(const ssdn_conv_args* a, const ConvGeom& g, ConvAux x, int nblk_y, hipStream_t s) {
     size_t lds = conv_lds(a, g, MT);
     if (lds > 160 * 1024) return ssdn_set_error("conv: tiling needs %zu B of LDS (> 160 KiB)", lds);
-    static bool attr_set = false;
+    static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
+    bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_conv<MT, BF, KS, CONV_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;

@@ -329,7 +329,8 @@ static int gd_launch(const ssdn_conv_args* a, hipStream_t s, const ssdn_conv_arg
     constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + NWP * NWM * 32 * (gd_eg(WM) * 64 + 16) + TM * 4 + 1024;
     static_assert(TP == 256 && NWP * NWM == 8, "gemm_dma_lds_bytes assumes 256-pixel tiles and 8 waves");
     static_assert(LDS <= 160 * 1024, "LDS");
-    static bool attr_set = false;
+    static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
+    bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_gdma<WP, WM, NWP, NWM, BF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;

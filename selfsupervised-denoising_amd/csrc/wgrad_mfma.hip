@@ -62,7 +62,8 @@ template <int MT, int CPW, int NL, bool BOTH, int PS, int KS, int RWX, int RWD>
 static int wgrad_launch(const ssdn_wgrad_args* a, const WgGeom& g, const WgAux& x, hipStream_t s) {
     size_t lds = 2 * ((size_t)g.XB + (size_t)g.DB) + WG_ONES_BYTES;
     if (lds > 160 * 1024) return ssdn_set_error("wgrad: tiling needs %zu B of LDS (> 160 KiB)", lds);
-    static bool attr_set = false;
+    static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
+    bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad<MT, CPW, NL, BOTH, PS, KS, RWX, RWD>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -159,7 +160,8 @@ int launch_wgrad_multi(const ssdn_wgrad_args* const* items, int n, hipStream_t s
             g_wg_multi_cache.push_back({tab, dtab, dev});
         }
     }
-    static bool attr_set = false;
+    static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
+    bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad_multi, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
@@ -178,7 +180,8 @@ __global__ __launch_bounds__(WGN_THREADS) void k_wgrad_thin(ssdn_wgrad_args a) {
 template <int MT>
 static int wgrad_thin_launch(const ssdn_wgrad_args* a, hipStream_t s) {
     const size_t lds = 2 * ((size_t)256 * wg_stride(MT * 64) + 18 * 18 * 16);
-    static bool attr_set = false;
+    static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
+    bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
         SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_wgrad_thin<MT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;

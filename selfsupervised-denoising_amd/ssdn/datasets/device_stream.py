@@ -85,11 +85,23 @@ class DevicePatchStream:
         self.generator = torch.Generator(device=self.device)
         if seed is None:
             seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())      # drawn from the (checkpointed) host RNG
+        self.rank = rank
         self.seed = seed + rank            # ranks never share a noise stream, whatever their host RNG states are
         self.generator.manual_seed(self.seed)
         self._calls = 0                    # Philox counter of SSDN_OP_NOISE: a fresh offset per minibatch
         self._static: Dict = {}            # metadata tensors that only depend on the batch shape
         self._denoiser = None
+
+    def state_dict(self) -> Dict:
+        """what a `.training` file needs to continue this stream: the Philox key (without the rank offset) and the number of minibatches
+        prepared so far (the counter part of the kernel's random-number offsets)"""
+        return {"seed": int(self.seed - self.rank), "calls": int(self._calls)}
+
+    def load_state_dict(self, sd: Dict, rank: Optional[int] = None):
+        self.rank = self.rank if rank is None else rank
+        self.seed = int(sd["seed"]) + self.rank
+        self._calls = int(sd["calls"])
+        self.generator.manual_seed(self.seed)
 
     def attach(self, denoiser):
         """Write every noisy minibatch straight into `denoiser`'s training input buffer (Denoiser.input_buffer): the pipeline

@@ -422,8 +422,13 @@ class DenoiserTrainer:
             else {"order": [], "index": 0}
         order = dict(order)
         order["index"] = self.state[StateValue.ITERATION]      # what was PROCESSED, not what the loader has prefetched
-        return {"denoiser": self.denoiser.state_dict(), "state": self.state, "train_order_iter": order,
-                "optimizer": self.denoiser.optimizer_state_dict(self.learning_rate), "rng": torch.get_rng_state()}
+        sd = {"denoiser": self.denoiser.state_dict(), "state": self.state, "train_order_iter": order,
+              "optimizer": self.denoiser.optimizer_state_dict(self.learning_rate), "rng": torch.get_rng_state()}
+        # (an extra key the reference's loader ignores) the device patch stream's Philox key and minibatch counter: a resumed run
+        # continues the noise stream instead of restarting it at offset 0 under a re-drawn key
+        if isinstance(self.trainloader, DevicePatchStream):
+            sd["device_stream"] = self.trainloader.state_dict()
+        return sd
 
     def load_state_dict(self, state_dict: Union[Dict, str]):
         if isinstance(state_dict, str):
@@ -433,6 +438,7 @@ class DenoiserTrainer:
         self.state = state_dict["state"]
         self._train_iter = SamplingOrder.from_state_dict(state_dict["train_order_iter"])
         self.denoiser.load_optimizer_state_dict(state_dict["optimizer"])
+        self._stream_state = state_dict.get("device_stream")
         torch.set_rng_state(state_dict["rng"])
         if self.world > 1 and self.rank > 0:
             # the file holds rank 0's generator state: the other ranks continue from a state derived from it, not from a copy
@@ -489,6 +495,9 @@ class DenoiserTrainer:
             dev = self.denoiser.device if self.denoiser is not None and hasattr(self.denoiser, "device") else \
                 torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
             loader = DevicePatchStream(loader, dataset, dev, rank=self.rank)
+            if getattr(self, "_stream_state", None):
+                loader.load_state_dict(self._stream_state, rank=self.rank)
+                self._stream_state = None
             if self.denoiser is not None and self.denoiser.device.type == "cuda":
                 loader.attach(self.denoiser)
         return loader, dataset, sampler

@@ -189,3 +189,25 @@ def test_device_patch_stream_uses_the_kernel_and_keeps_the_batch_format():
         again = DevicePatchStream(None, nd, "cuda:0", seed=1)
         first, second = again.prepare(u8.pin_memory(), idx)[0], again.prepare(u8.pin_memory(), idx)[0]
         assert torch.equal(first, gpu[0]) and not torch.equal(first, second)
+
+
+def test_device_patch_stream_state_continues_the_noise_stream():
+    """the `.training` state of the stream (Philox key + minibatch counter): a stream restored after minibatch 1 produces minibatches
+    2 and 3 of the original run bit for bit (the counter was not checkpointed)"""
+    from ssdn.datasets import DevicePatchStream, NoisyDataset
+    from ssdn.params import NoiseAlgorithm
+    nd = NoisyDataset(None, "gauss5_50", NoiseAlgorithm.NOISE_TO_VOID, pad_uniform=False, pad_multiple=32, square=True, training_mode=True)
+    u8 = torch.randint(0, 256, (4, 3, 64, 64), dtype=torch.uint8)
+    idx = torch.arange(4)
+    a = DevicePatchStream(None, nd, "cuda:0", seed=11, rank=2)
+    first = a.prepare(u8.pin_memory(), idx)[0].clone()
+    sd = a.state_dict()
+    assert sd == {"seed": 11, "calls": 1}
+    want = [a.prepare(u8.pin_memory(), idx)[0].clone() for _ in range(2)]
+    b = DevicePatchStream(None, nd, "cuda:0", seed=999, rank=2)
+    b.load_state_dict(sd)
+    got = [b.prepare(u8.pin_memory(), idx)[0].clone() for _ in range(2)]
+    assert all(torch.equal(w, g) for w, g in zip(want, got)) and not torch.equal(first, got[0])
+    other_rank = DevicePatchStream(None, nd, "cuda:0", seed=999, rank=0)
+    other_rank.load_state_dict(sd, rank=3)
+    assert not torch.equal(other_rank.prepare(u8.pin_memory(), idx)[0], want[0])       # ranks never share a stream
