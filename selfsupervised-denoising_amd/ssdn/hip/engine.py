@@ -120,6 +120,14 @@ class DeviceNet:
         for i, op in enumerate(plan.bwd):
             if op.type == "wgrad":
                 flush[gof(op)] = i
+        lane_of = {}
+        for g in list(flush):
+            _, lane, after = plan.wgrad_group_info(g)
+            lane_of[g] = MEGA_LANE if lane is None else lane
+            if after is not None:              # behind that layer's data-gradient launch (never in front of the group's last operand)
+                at = [i for i, op in enumerate(plan.bwd) if op.type == "conv" and op.a["role"] == "dgrad" and op.a["layer"] == after]
+                if at:
+                    flush[g] = max(flush[g], at[0])
         def chainable(op):
             if op.type == "conv":
                 px = op.a["H"] * op.a["W"]
@@ -149,11 +157,11 @@ class DeviceNet:
                     continue
                 for op2, rec2 in zip(plan.bwd, recs):
                     if op2.type == "wgrad" and gof(op2) == g:
-                        out.append((rec2[0], rec2[1], MEGA_LANE))
+                        out.append((rec2[0], rec2[1], lane_of[g]))
                         names.append(None)
                 for op2, rec2 in zip(plan.bwd, recs):
                     if op2.type == "wreduce" and gof(op2) == g:
-                        out.append((rec2[0], rec2[1], MEGA_LANE))
+                        out.append((rec2[0], rec2[1], lane_of[g]))
                         names.append(op2.a["layer"])
         return out, names
 

@@ -28,7 +28,9 @@ WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient 
 # workgroup per CU, every op's grid sized by the cost model below so that all workgroups finish together.
 #   "all": one launch behind the last data gradient; "buckets": one per gradient bucket (ssdn.hip.dp.bucket_layers);
 #   None: round 3's per-layer launches on the side lane
-WGRAD_MEGA = "all"
+WGRAD_MEGA = "split"
+SPLIT_HEAD_CUS = (1, 2)       # "split": share of the CUs the side-lane launch is planned for
+SPLIT_GROUP0 = ("output_block", "decode_block_2.2")   # "split": layers (name prefixes) of the side-lane launch; their operands must exist behind decode_block_2.0's data gradient
 # cost model of one weight-gradient block, in cycles (calibrated on BASELINE config 2 with tools/wgrad_calib.py):
 #   K-step of 16 pixels = base + per_mfma * MT * CPW;  a block = tiles * ksteps * K-step + fixed + slab bytes / slab_rate
 MEGA_COST = {
@@ -632,12 +634,24 @@ class NetPlan:
     # ---- chip-wide weight-gradient launches ------------------------------------------------------------------
     def wgrad_group_of(self, layer_name: str) -> int:
         """index of the chip-wide launch the weight gradients of `layer_name` belong to (WGRAD_MEGA)"""
+        if WGRAD_MEGA == "split":
+            return 0 if layer_name.startswith(SPLIT_GROUP0) else 1
         if WGRAD_MEGA != "buckets":
             return 0
         off = {l.name: l.w_off for l in self.layers}
         a, b = off["decode_block_1.0"], off["decode_block_5.0"]        # (== ssdn.hip.dp.bucket_layers)
         w = off[layer_name]
         return 0 if w >= a else (1 if w >= b else 2)
+
+    def wgrad_group_info(self, g: int):
+        """(workgroups the launch of group g is planned for, lane, name of the layer whose DATA-GRADIENT launch it follows or None =
+        where the group's last operand appears).  "split": the head layers' weight gradients (a fifth of the work, operands ready
+        at the start of the backward pass) run on HALF the CUs on the side lane next to the latency-bound bottom of the U (the
+        16x16 layers and the chained 8x8..2x2 layers: ~270 us of launches that cannot fill the chip); everything else as one
+        launch on all CUs behind the last data gradient."""
+        if WGRAD_MEGA == "split" and g == 0:
+            return max(1, (self.cus * SPLIT_HEAD_CUS[0]) // SPLIT_HEAD_CUS[1]), 1, "decode_block_2.0"
+        return self.cus, None, None
 
     @staticmethod
     def _thin_ok(a) -> bool:
@@ -697,12 +711,12 @@ class NetPlan:
     def _plan_mega(self):
         """Size the grid of every weight-gradient op so that the workgroups of its chip-wide launch (one per CU) finish together,
         allocate the slabs, and give every op its cost per block (the library packs the blocks onto the workgroups by it)."""
-        W = self.cus
         groups: Dict[int, list] = {}
         for op, reds in self._mega_ops:
             groups.setdefault(self.wgrad_group_of(op.a["layer"]), []).append((op, reds))
         self.mega_makespan = {}
         for gi, members in sorted(groups.items()):
+            W = self.wgrad_group_info(gi)[0]
             cand = []
             for op, reds in members:
                 tile, ntiles, c_tile, fixed = self._mega_candidates(op.a)

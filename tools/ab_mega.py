@@ -11,7 +11,9 @@ from ssdn.datasets import DevicePatchStream, NoisyDataset
 from ssdn.params import NoiseAlgorithm
 
 dev = torch.device("cuda", 0)
-VARIANTS = {"per_layer_lanes": (None, 1), "mega_all_lane0": ("all", 0), "mega_buckets_lane0": ("buckets", 0), "mega_buckets_lane1": ("buckets", 1),
+VARIANTS = {"per_layer_lanes": (None, 1), "mega_all_lane0": ("all", 0), "mega_split_half": ("split", 0, (1, 2)), "mega_split_3_8": ("split", 0, (3, 8)),
+            "mega_split_5_8": ("split", 0, (5, 8)), "split_half_dec2": ("split", 0, (1, 2), ("output_block", "decode_block_2")),
+            "split_5_8_dec2": ("split", 0, (5, 8), ("output_block", "decode_block_2")), "split_half_dec22": ("split", 0, (1, 2), ("output_block", "decode_block_2.2")), "mega_buckets_lane0": ("buckets", 0), "mega_buckets_lane1": ("buckets", 1),
             "mega_all_lane1": ("all", 1)}
 if len(sys.argv) > 1:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1:]}
@@ -20,10 +22,13 @@ g = torch.Generator().manual_seed(1)
 u8 = [torch.randint(0, 256, (32, 3, 64, 64), generator=g, dtype=torch.uint8).pin_memory() for _ in range(4)]
 idx = torch.arange(32)
 runs = {}
-for v, (mode, lane) in VARIANTS.items():
+for v, spec in VARIANTS.items():
+    mode, lane = spec[0], spec[1]
     torch.manual_seed(0)
     G.WGRAD_MEGA = mode
     E.MEGA_LANE = lane
+    G.SPLIT_HEAD_CUS = spec[2] if len(spec) > 2 else (1, 2)
+    G.SPLIT_GROUP0 = spec[3] if len(spec) > 3 else ("output_block",)
     d = Denoiser(B.make_cfg(), device=str(dev))
     d.train()
     stream = DevicePatchStream(None, nd, dev, seed=1).attach(d)
