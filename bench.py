@@ -396,7 +396,7 @@ def run_rank(args):
         # HBM-side traffic of the same kernel family: PMC passes cannot run inside this process, so the per-launch figure is
         # the committed result of tools/pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE); null if absent
         traffic, traffic_src = None, None
-        for cand in ("r03_traffic.json", "r02_traffic.json"):      # the committed PMC summary of THIS kernel (tools/pmc_traffic.sh)
+        for cand in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):      # the committed PMC summary of THIS kernel (tools/pmc_traffic.sh)
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     tj = json.load(f)
@@ -435,7 +435,7 @@ def run_rank(args):
             wg = families.get("wgrad")
             if wg and wg.get("tflops_algorithmic"):
                 res["roofline"]["second_kernel"] = {
-                    "kernel": "k_wgrad_mega: weight + bias gradients of all 20 layers as one launch, one block per (op, pixel partition), a block owns its CU",
+                    "kernel": "k_wgrad_mega, the chip-wide launch: weight + bias gradients of every layer but the head's (those: families.wgrad_side, a half-chip launch on the side lane under the latency-bound bottom of the U), one block per (op, pixel partition), a block owns its CU",
                     "bound": "mfma", "achieved": wg["tflops_algorithmic"], "peak": MFMA_FP16_DENSE_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(wg["tflops_algorithmic"] / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "avg_launch_us": wg["avg_launch_us"],
                     "launches_per_step": wg["launches_per_step"],

@@ -470,7 +470,8 @@ int ssdn_device_cus(void);
 #define SSDN_PROF_GEMM 4      /* k_gdma: 1x1 layers as one-pass LDS-DMA GEMMs */
 #define SSDN_PROF_CDMA_MT3 5  /* k_cdma<3,*>: the persistent LDS-DMA 3x3 kernel on 96-channel blocks (the dominant kernel) */
 #define SSDN_PROF_CDMA_MT21 6 /* k_cdma<2,*>, k_cdma<1,*> */
-#define SSDN_PROF_KINDS 7
+#define SSDN_PROF_WGRAD_SIDE 7 /* a k_wgrad_mega launch planned for fewer workgroups than the device has CUs (the side-lane launch) */
+#define SSDN_PROF_KINDS 8
 int ssdn_profile_enable(int kind, int max_launches);
 int ssdn_profile_set_stride(int kind, int stride);
 int ssdn_profile_read(int kind, double* total_ms, long long* launches, double* flops, double* bytes);

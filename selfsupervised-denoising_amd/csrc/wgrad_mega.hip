@@ -205,9 +205,10 @@ int launch_wgrad_mega(const ssdn_wgrad_args* const* ops, int n, hipStream_t s) {
         attr_set[dev] = true;
     }
     if (lds > 160 * 1024) return ssdn_set_error("wgrad: merged launch needs %zu B of LDS", lds);
-    prof_begin(SSDN_PROF_WGRAD, s);
+    const int prof_kind = W < ssdn_device_cus() ? SSDN_PROF_WGRAD_SIDE : SSDN_PROF_WGRAD;
+    prof_begin(prof_kind, s);
     SSDN_LAUNCH(k_wgrad_mega, dim3((unsigned)items.size()), dim3(WG_THREADS), lds, s, (const WgMegaEntry*)dtab, (const WgMegaItem*)(dtab + off_items));
-    prof_end(SSDN_PROF_WGRAD, s, flops, bytes);
+    prof_end(prof_kind, s, flops, bytes);
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;
 }

@@ -134,7 +134,7 @@ SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
            "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_chain_len",
            "ssdn_conv_set_chain", "ssdn_wgrad_mega_ok", "ssdn_wgrad_variant"]
-PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6)
+PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6, wgrad_side=7)
 
 _lib = None
 

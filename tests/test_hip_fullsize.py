@@ -253,3 +253,29 @@ def test_eval_sizes_forward_vs_oracle(P):
     assert float((o - r["out"]).norm() / r["out"].norm()) <= 5e-3
     for b in range(B):
         assert abs(float(R.psnr(o[b:b + 1], clean[b:b + 1]) - R.psnr(r["out"][b:b + 1], clean[b:b + 1]))) <= 0.05
+
+
+def test_full_size_config2_properties():
+    """Size-independent properties at the bench workload's size (config 2, batch 32, 64x64): the whole step is BIT-reproducible -- two
+    runs of forward + loss + backward from the same weights give identical loss and identical gradients (no floating-point atomics
+    anywhere; the chip-wide weight-gradient launch hands blocks to CUs in whatever order they free up, every block owns its slab, the
+    slabs are summed in a fixed order) -- and a second Denoiser built from the same seed reproduces them."""
+    import fullsize as F
+    from ssdn.datasets import NoisyDataset
+    from ssdn.params import PipelineOutput
+    alg, style, mode, B, P = F.CASES["cfg2"]
+    clean, noisy, npar = F.inputs("cfg2")
+    MD = NoisyDataset.Metadata
+    res = []
+    for rep in range(2):
+        torch.manual_seed(21)
+        d = make_denoiser(alg, style, mode, 3)
+        d.train()
+        for again in range(2):
+            out = d.run_pipeline([noisy, clean, {MD.INPUT_NOISE_VALUES: npar, MD.CLEAN: clean}])
+            d.backward()
+            torch.cuda.synchronize()
+            res.append((out[PipelineOutput.LOSS].detach().cpu().clone(), d.flat_grad.detach().cpu().clone()))
+    assert torch.isfinite(res[0][1]).all() and float(res[0][1].abs().max()) > 0
+    for loss, grad in res[1:]:
+        assert torch.equal(loss, res[0][0]) and torch.equal(grad, res[0][1])

@@ -10,7 +10,7 @@ rm -rf $OUT; mkdir -p $OUT
 cd /tmp
 STEPS=4; WARM=2
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 250 rocprofv3 --pmc $c --kernel-trace -d $OUT/$c -o t --output-format csv -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > $OUT/$c.log 2>&1
+  timeout 250 rocprofv3 --pmc $c --kernel-trace -d $OUT/$c -o t --output-format csv -- python $R/bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-trainer-leg > $OUT/$c.log 2>&1
 done
 python - "$OUT" $STEPS $WARM <<'PY'
 import csv, sys, glob, collections, json, re, subprocess, datetime
@@ -21,7 +21,7 @@ def family(k):
     if not m: return None
     name, t = m.group(1), m.group(2) or ""
     if name == "k_cdma": return "k_cdma<3,*>" if t.startswith("<3") else "k_cdma<2|1,*>"
-    if name in ("k_conv", "k_gdma", "k_wgrad_multi"): return name
+    if name in ("k_conv", "k_gdma", "k_wgrad_multi", "k_wgrad_mega"): return name
     if name.startswith("k_wgrad"): return "k_wgrad"            # k_wgrad<...>, k_wgrad_thin<MT>
     if name.startswith("k_wreduce"): return "k_wreduce*"
     return "elementwise/head/adam"
@@ -57,7 +57,7 @@ j = {"kernel": "k_cdma<3,*> (every launch of the bench workload: decode_block_1.
      "fetch_correction": 2.0, "steps_profiled": nst,
      "families": table,
      "total_hbm_mb_per_step": round(sum(t["hbm_mb_per_step"] for t in table.values()), 1),
-     "collected_at": "round 3, " + datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),
+     "collected_at": "round 4, " + datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),
      "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16 B/lane coalesced reads on gfx950; WRITE_SIZE as reported (calibrated in round 1 on the weight-gradient slabs). Infinity-Cache hits are counted, not excluded."}
 json.dump(j, open(out + "/traffic.json", "w"), indent=1)
 print(json.dumps(j, indent=1))

@@ -10,6 +10,9 @@ from ssdn.hip import graph as G
 from ssdn.hip.engine import DeviceNet, OpList, current_stream
 from ssdn.hip.graph import NetPlan
 
+# the cost model is calibrated on ONE launch holding every op (the production plan, "split", runs two launches: WGRAD_MEGA=split)
+G.WGRAD_MEGA = os.environ.get("WGRAD_MEGA", "all")
+
 
 def time_list(ol, iters=10):
     s = current_stream()
