@@ -431,7 +431,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
 
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 static bool g_chain_on = true;
-extern "C" int ssdn_conv_set_chain(int on) { g_chain_on = on != 0; return 0; }
+static int g_chain_max_px = 256;          // largest image (pixels) a chained launch takes (ssdn_conv_set_chain(2): 64 -- A/B aid)
+extern "C" int ssdn_conv_set_chain(int on) { g_chain_on = on != 0; g_chain_max_px = on == 2 ? 64 : 256; return 0; }
 bool chain_merging_on() { return g_chain_on; }
 
 static int ilog2_exact(int v) {
@@ -525,7 +526,7 @@ static bool chain_conv_ok(const ssdn_conv_args* a, const ssdn_conv_args* first) 
     if (conv_validate(a)) return false;
     if (a->bf16 != first->bf16 || a->ntaps != 9 || a->dst32 || a->unrot.p) return false;
     if (a->kc != 48 || a->Ktot % 48 || a->c0 % 48 || a->c1 % 48 || a->Ktot <= 0) return false;
-    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || a->H * a->W > 256 || a->H * a->W == 128) return false;
+    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || a->H * a->W > g_chain_max_px || a->H * a->W == 128) return false;
     if (a->H * a->W > 64 && (a->Mpad > 64 || a->Ktot > 48 || a->upsum.p)) return false;   // 256 pixels: only the thin (48-channel) layers pay
     if ((a->M & 7) || a->Mpad > 32 * 8 || a->N != first->N) return false;
     if (a->up0 && (a->c0 == 0 || ((a->H | a->W) & 1))) return false;
@@ -547,7 +548,7 @@ static bool chain_conv_ok(const ssdn_conv_args* a, const ssdn_conv_args* first) 
 }
 static bool chain_pool_ok(const ssdn_pool_args* a, int N) {
     if ((a->C & 7) || (a->H & 1) || (a->W & 1) || a->N != N) return false;
-    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || (a->H / 2) * (a->W / 2) > 256) return false;
+    if (ilog2_exact(a->H) < 0 || ilog2_exact(a->W) < 0 || (a->H / 2) * (a->W / 2) > g_chain_max_px) return false;
     for (const ssdn_view* v : {&a->act, &a->dpool, &a->dz})
         if (!v->p || (v->cs & 7) || (v->co & 7)) return false;
     return true;

@@ -29,6 +29,8 @@ WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient 
 #   "all": one launch behind the last data gradient; "buckets": one per gradient bucket (ssdn.hip.dp.bucket_layers);
 #   None: round 3's per-layer launches on the side lane
 WGRAD_MEGA = "split"
+MEGA_MIN_PX = 32768           # networks with fewer pixels (N*H*W) at full resolution keep the per-layer launches: a handful of tiles per
+                              # layer is latency, not throughput (config 1's shape, batch 4 at 32x32: 0.66 ms per step vs 0.70 / 0.77)
 SPLIT_HEAD_CUS = (1, 2)       # "split": share of the CUs the side-lane launch is planned for
 SPLIT_GROUP0 = ("output_block", "decode_block_2.2")   # "split": layers (name prefixes) of the side-lane launch; their operands must exist behind decode_block_2.0's data gradient
 # cost model of one weight-gradient block, in cycles (calibrated on BASELINE config 2 with tools/wgrad_calib.py):
@@ -368,7 +370,7 @@ class NetPlan:
         # tile it can prefetch.)
         slab_bytes = ntaps * Mpad * Kpad * 4
         ctiles = ntaps * Kpad // 32 + 1
-        if WGRAD_MEGA and self.cus >= 64:
+        if WGRAD_MEGA and self.cus >= 64 and self.N * self.H * self.W >= MEGA_MIN_PX:
             # planned later, together with the other ops of its launch (_plan_mega): grid, tile, slabs, cost
             self.nwgrad = getattr(self, "nwgrad", 0) + 1
             op = Op("wgrad", dict(layer=layer.name, dz=dz, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,

@@ -37,8 +37,19 @@ def test_backward_list_order_invariants(cin, cout, bs, B, P):
                     assert pos[j] < pos[i]
         else:
             assert names[pos[i]] is None
-    # 4. a gradient bucket's reductions are one consecutive run (the executor merges it into two launches)
+    # 4. the reductions of a gradient bucket (per-layer plans) / of a chip-wide launch group (graph.WGRAD_MEGA) are one consecutive run
+    #    (the executor merges a run into two launches)
     buckets = bucket_layers(plan.layers)
+    if getattr(plan, "_mega_ops", None):
+        groups = {}
+        for l in plan.layers:
+            groups.setdefault(plan.wgrad_group_of(l.name), set()).add(l.name)
+        buckets = list(groups.values())
+        # ... and a group's weight-gradient records are consecutive too (ONE k_wgrad_mega launch), directly in front of its reductions
+        for b in buckets:
+            kw = sorted(pos[i] for i, op in enumerate(plan.bwd) if op.type == "wgrad" and op.a["layer"] in b)
+            kr = sorted(pos[i] for i, op in enumerate(plan.bwd) if op.type == "wreduce" and op.a["layer"] in b)
+            assert kw == list(range(kw[0], kw[0] + len(kw))) and kr[0] == kw[-1] + 1
     for b in buckets:
         ks = sorted(pos[i] for i, op in enumerate(plan.bwd) if op.type == "wreduce" and op.a["layer"] in b)
         if ks:

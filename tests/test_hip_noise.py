@@ -191,6 +191,7 @@ def test_device_patch_stream_uses_the_kernel_and_keeps_the_batch_format():
         assert torch.equal(first, gpu[0]) and not torch.equal(first, second)
 
 
+@pytest.mark.gpu
 def test_device_patch_stream_state_continues_the_noise_stream():
     """the `.training` state of the stream (Philox key + minibatch counter): a stream restored after minibatch 1 produces minibatches
     2 and 3 of the original run bit for bit (the counter was not checkpointed)"""

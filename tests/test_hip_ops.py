@@ -405,7 +405,7 @@ def test_full_size_config2_properties():
     assert not bad, "\n".join(bad)
 
 
-@pytest.mark.parametrize("B,P,mode", [(2, 32, "all"), (32, 64, "all"), (2, 32, None), (4, 64, "buckets")])
+@pytest.mark.parametrize("B,P,mode", [(2, 32, "all"), (32, 64, "all"), (2, 32, None), (4, 64, "buckets"), (32, 64, "split"), (4, 128, "split")])
 def test_merged_weight_gradient_launch_is_bit_identical(B, P, mode, monkeypatch):
     """A run of consecutive SSDN_OP_WGRAD ops executes as ONE launch -- the chip-wide k_wgrad_mega (csrc/wgrad_mega.hip: one workgroup
     per CU works through a list of blocks of several ops' grids) or, for round 3's per-layer plans, k_wgrad_multi for the small layers;
@@ -416,6 +416,7 @@ def test_merged_weight_gradient_launch_is_bit_identical(B, P, mode, monkeypatch)
     from ssdn.hip.engine import DeviceNet, OpList, current_stream
     from ssdn.hip.graph import NetPlan
     monkeypatch.setattr(G, "WGRAD_MEGA", mode)
+    monkeypatch.setattr(G, "MEGA_MIN_PX", 0)                  # (the small fixture too)
     dev = torch.device("cuda:0")
     plan = NetPlan("m/", 3, 9, True, B, P, P, cus=L.load().ssdn_device_cus())
     g = torch.Generator(device="cpu").manual_seed(11)

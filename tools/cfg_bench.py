@@ -18,6 +18,10 @@ CONFIGS = [  # tag, algorithm, style, noise value, channels, per-GPU batch, patc
     ("config 1 shape on the device: n2c gauss25 mono, 32x32, batch 4", "n2c", "gauss25", "known", 1, 4, 32),
 ]
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+if os.environ.get("WGRAD_MEGA"):          # A/B aid: plan variant ("all", "split", "buckets", "none")
+    from ssdn.hip import graph as _G
+    _G.WGRAD_MEGA = None if os.environ["WGRAD_MEGA"] == "none" else os.environ["WGRAD_MEGA"]
+    print("WGRAD_MEGA =", _G.WGRAD_MEGA)
 dev = torch.device("cuda", 0)
 for tag, alg, style, mode, ch, B, P in CONFIGS:
     cfg = ssdn.cfg.base()
