@@ -702,6 +702,12 @@ static WgItems wgrad_items(const ssdn_wgrad_args* a, const WgGeom& g) {
     else if (ix <= 6 && (single || (t.rswx <= steps && t.rswd <= steps))) { t.nl = 6; t.both = 1; }
     return t;
 }
+// the compile-time schedules of the layers with <= 48 input channels (an input row = 18 pixels x 6 pieces = 108 pieces) take TWO 64-lane
+// loads per row instead of four (half of which repeated earlier pieces): half the staging instructions of these classes
+static inline bool wgrad_nl2(const ssdn_wgrad_args* a, const WgGeom& g, int MT, int CPW) {
+    const int ix = (g.HW * (a->Ktot / 8) + 63) / 64;
+    return ix <= 2 && CPW == 5 && (MT == 2 || MT == 3);
+}
 struct WgPrep { WgGeom g; WgAux x; WgItems wi; int MT, CPW, gx, gy; size_t lds; };
 static int wgrad_prepare(const ssdn_wgrad_args* a, WgPrep* p) {
     int rc = wgrad_validate(a);

@@ -27,7 +27,8 @@ struct WgMegaItem { int entry, bx, by, pad; };
     X(3, 3, 4, 6, true, 832, 4, 2, 2) X(4, 3, 4, 4, false, 0, 0, 0, 0) X(5, 3, 5, 4, false, 0, 0, 0, 0) \
     X(6, 2, 5, 4, false, 0, 0, 0, 0) X(7, 1, 1, 4, false, 0, 0, 0, 0) X(8, 3, 1, 4, false, 0, 0, 0, 0) \
     X(10, 3, 5, 6, true, 0, 0, 0, 0) X(11, 2, 5, 6, true, 0, 0, 0, 0) \
-    X(12, 3, 4, 6, true, 0, 0, 0, 0) X(13, 1, 1, 6, true, 0, 0, 0, 0) X(14, 3, 1, 6, true, 0, 0, 0, 0)
+    X(12, 3, 4, 6, true, 0, 0, 0, 0) X(13, 1, 1, 6, true, 0, 0, 0, 0) X(14, 3, 1, 6, true, 0, 0, 0, 0) \
+    X(15, 3, 5, 2, false, 192, 8, 3, 2) X(16, 2, 5, 2, false, 192, 8, 3, 2)
 // One block per ITEM, items in descending order of cost: the hardware hands the next block to the next CU that frees up (a
 // weight-gradient workgroup owns its CU), i.e. it performs the longest-first packing itself, with the true run times.
 // The tables are read through the CONSTANT address space, like kernel arguments: the entry's fields then are invariant scalar loads
@@ -84,7 +85,7 @@ static WgVariant wgrad_variant(const ssdn_wgrad_args* a, const WgPrep& p) {
     v.nl = wi.both ? 6 : 4; v.both = wi.both ? 1 : 0;
     if (st4b && v.mt == 3 && v.cpw == 4) { v.ps = 832; v.ks = 4; v.rwx = 2; v.rwd = 2; }
     else if (wi.both) {}
-    else if (st8 && v.mt >= 2 && v.cpw >= 2) { v.ps = 192; v.ks = 8; v.rwx = 3; v.rwd = 2; }
+    else if (st8 && v.mt >= 2 && v.cpw >= 2) { v.ps = 192; v.ks = 8; v.rwx = 3; v.rwd = 2; if (wgrad_nl2(a, g, v.mt, v.cpw)) v.nl = 2; }
     else if (st16 && v.mt >= 2 && v.cpw <= 3) { v.ps = 64; v.ks = 16; v.rwx = 5; v.rwd = 4; }
     return v;
 }

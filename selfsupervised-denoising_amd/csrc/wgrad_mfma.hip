@@ -224,6 +224,12 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     const bool st4b = wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
     // (a static variant is only instantiated for the (mt, cpw) it is used with: elsewhere its template arguments collapse to
     //  the generic kernel's)
+    if (st8 && wgrad_nl2(a, g, MT, CPW)) {
+        rc = MT == 2 ? wgrad_launch<2, 5, 2, false, 192, 8, 3, 2>(a, g, x, s) : wgrad_launch<3, 5, 2, false, 192, 8, 3, 2>(a, g, x, s);
+        if (rc) return rc;
+        SSDN_CHECK_HIP(hipGetLastError());
+        return 0;
+    }
 #define WG_S8(mt, cpw) ((mt) >= 2 && (cpw) >= 2)
 #define WG_S16(mt, cpw) ((mt) >= 2 && (cpw) <= 3)
 #define WG_S4B(mt, cpw) ((mt) == 3 && (cpw) == 4)

@@ -102,9 +102,9 @@ class DeviceNet:
                     recs.append(("event_record", L.EventArgs(events[k])))
         ol = OpList.__new__(OpList)
         OpList.__init__(ol, recs, lanes=True)
-        for j, r in enumerate(recs):                       # the record rides the weight-gradient lane
+        for j, r in enumerate(recs):                       # the record rides the lane of the reduction it follows
             if r[0] == "event_record":
-                ol.arr[j].lane = 1
+                ol.arr[j].lane = ol.arr[j - 1].lane if j > 0 else 0
         return ol
 
     @staticmethod

@@ -39,6 +39,7 @@ MEGA_COST = {
     # measured INSIDE the chip-wide launch of BASELINE config 2 (every CU streaming; tools/wgrad_calib.py trace: per-block
     # s_memrealtime stamps), in cycles of a nominal 2.1 GHz clock.  On a quiet chip the same blocks run ~1.45x faster.
     "static": (342.0, 38.8),      # compile-time staging schedules (3x3 layers, 16x8-pixel tiles): 4.4 us per (3,7) tile
+    "static2": (258.0, 40.2),     # ... of the layers with <= 48 input channels (two loads per input row: csrc/wgrad_body.h::wgrad_nl2)
     "generic": (1350.0, 53.0),    # run-time staging (small layers, odd tiles)
     "head": (1208.0, 0.0),        # 1x1 layers over four 96-channel input blocks (an input AND a dZ row per K-step)
     "head_mb": (1208.0, 0.0),     # ... with the 4 output blocks of a pixel partition side by side (input shared through L2)
@@ -701,6 +702,8 @@ class NetPlan:
             kind = "head_mb" if a["mblocks"] > 1 else "head"
         else:
             kind = "static" if static else "generic"
+            if static and ix <= 2 and cpw == 5:
+                kind = "static2"
         # the run-time-staged variants with 21 accumulators per wave are not part of the chip-wide launch (register budget): such an
         # op runs as two column groups (every tile is staged by two blocks; these are the layers with few pixels)
         G = 2 if (kind == "generic" and MT * cpw > 16) else 1
