@@ -101,3 +101,39 @@ def test_plan_tilings_fit_lds():
                 lds = NP * (a["kc"] * 2 + 16) + 2 * min(3, a["Mpad"] // 32) * 32 * (a["kc"] * 2 + 16)
                 assert lds <= LDS_LIMIT
                 assert a["ltw"] + a["lth"] + a["ltn"] <= 8
+
+
+def test_every_baseline_weight_gradient_op_has_an_instance_in_the_chip_wide_launch():
+    """graph.WGRAD_MEGA plans: every SSDN_OP_WGRAD of the BASELINE configurations (and of the sigma-estimation net) must be runnable as
+    an entry of k_wgrad_mega (csrc/wgrad_mega.hip instantiates a curated set of kernel variants; an op without one would silently fall
+    back to a launch of its own), the planner's cost-model class must be the variant the library picks, and the blocks of a launch
+    group must add up to what the plan was made for."""
+    import ctypes as C
+    from ssdn.hip import graph as G
+    from ssdn.hip import lib as L
+    from ssdn.hip.engine import DeviceNet
+    lib = L.load()
+    for (cin, cout, bs, B, P) in [(3, 9, True, 32, 64), (3, 9, True, 16, 128), (3, 1, False, 32, 64), (3, 3, False, 32, 64), (1, 2, True, 32, 64)]:
+        plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=256)
+        assert getattr(plan, "_mega_ops", None), "the BASELINE sizes use the chip-wide plan"
+        flat = torch.zeros(plan.nparams)
+        dn = DeviceNet(plan, torch.device("cpu"), flat, torch.zeros_like(flat))
+        blocks = {}
+        for op in plan.bwd:
+            if op.type != "wgrad":
+                continue
+            rec = dn._mat(op)
+            v = (C.c_int32 * 9)()
+            inst = lib.ssdn_wgrad_variant(C.byref(rec[1]), v)
+            assert inst >= 0 and lib.ssdn_wgrad_mega_ok(C.byref(rec[1])) == 1, (op.a["layer"], op.a["Ktot"], list(v), lib.ssdn_last_error())
+            thin, mt, cpw, nl, both, ps, ks = list(v)[:7]
+            tile, ntiles, c_tile, fixed = plan._mega_candidates(dict(op.a))
+            if not thin and ks == 8 and not both:           # compile-time schedule: the planner must have priced it as one
+                base = G.MEGA_COST["static2" if nl == 2 else "static"]
+                assert c_tile == pytest.approx(8 * (base[0] + base[1] * mt * cpw)), (op.a["layer"], list(v))
+            g = plan.wgrad_group_of(op.a["layer"])
+            blocks[g] = blocks.get(g, 0) + op.a["nslabs"] * max(1, op.a["mblocks"]) * max(1, op.a["csplit"])
+            assert op.a["mega"] == plan.wgrad_group_info(g)[0]
+        for g, n in blocks.items():
+            W = plan.wgrad_group_info(g)[0]
+            assert n >= W // 2, "a launch group with far fewer blocks than CUs wastes the chip (%d blocks for %d)" % (n, W)
