@@ -233,10 +233,11 @@ typedef struct ssdn_wgrad_args {
     int32_t kreal;         /* real (un-padded) input channels among the Ktot slots, or 0 (unknown).  1..3 real channels under a
                               3x3 window (the network's first layer and the image half of decode_block_1.0) are served by the
                               im2col kernel k_wgrad_thin: 9 * kreal + 1 <= 32 GEMM columns instead of 9 x 32 */
-    int32_t mega;          /* > 0: the op is planned as part of ONE chip-wide launch of `mega` workgroups (one per CU) together with
-                              the SSDN_OP_WGRAD ops next to it in the list that carry the same value: every block of every op's
-                              grid becomes an item, items are packed onto the workgroups longest first by `cost`; each item runs
-                              the code of its op's own launch (bit-identical slabs).  0: the op is launched on its own */
+    int32_t mega;          /* > 0: the op is planned as part of ONE merged launch (k_wgrad_mega) together with the SSDN_OP_WGRAD ops next
+                              to it in the list that carry the same value (the number of CUs the planner sized the group's grids
+                              for): every block of every op's grid becomes one block of the merged launch, sorted by `cost`,
+                              longest first, so that the CUs pick them up in that order; each block runs the code of its op's own
+                              launch (bit-identical slabs).  0: the op is launched on its own */
     float cost;            /* planner's estimate of the time of ONE block of this op's grid, any unit (only the ratios matter) */
 } ssdn_wgrad_args;
 

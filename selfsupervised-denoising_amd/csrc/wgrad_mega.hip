@@ -8,12 +8,12 @@ namespace { std::mutex g_wg_multi_mutex; }
 // 25 launches per step, each a persistent grid that fills the chip for 20-110 us, pay 25 prologues (first tile fetched
 // synchronously), 25 slab writes of up to 332 KB per workgroup and 25 ragged tails; the layers at the bottom of the U cannot fill the
 // chip at all.  A weight-gradient workgroup owns its CU anyway (512 registers per lane on every SIMD), so the natural unit is the CU:
-// k_wgrad_mega is ONE grid of `mega` workgroups (one per CU), each executing a LIST of items; an item is one block (bx, by) of one
-// op's own launch grid and runs exactly the code that launch would run (same template instance, same (bx, by, gdx): bit-identical
-// slabs).  The planner (ssdn/hip/graph.py) sizes every op's grid from its cost model so that the items of one launch add up to equal
+// k_wgrad_mega is ONE grid with a block per ITEM; an item is one block (bx, by) of one op's own launch grid and runs exactly the code
+// that launch would run (same template instance, same (bx, by, gdx): bit-identical slabs).  The planner (ssdn/hip/graph.py) sizes every op's grid from its cost model so that the items of one launch add up to equal
 // times -- a layer with 27 % of the work gets 27 % of the CUs for the whole launch instead of all CUs for 27 % of the time, which
 // divides the number of slabs (written, then read back by SSDN_OP_WREDUCE) by the number of layers -- and gives each op its estimated
-// cost per block (ssdn_wgrad_args.cost); the packing below (longest item first onto the least loaded workgroup) is deterministic.
+// cost per block (ssdn_wgrad_args.cost); the items are sorted by it, longest first (stable: deterministic tables), and the hardware
+// hands them to the CUs in that order.
 struct WgMegaEntry {
     ssdn_wgrad_args a;
     WgAux x;
@@ -140,7 +140,7 @@ int launch_wgrad_mega(const ssdn_wgrad_args* const* ops, int n, hipStream_t s) {
     if (W < 1 || W > 4096) return ssdn_set_error("wgrad: bad mega grid %d", W);
     std::vector<WgMegaEntry> ent((size_t)n);
     memset(ent.data(), 0, sizeof(WgMegaEntry) * (size_t)n);
-    struct It { double cost; int e, bx, by, xcd; };
+    struct It { double cost; int e, bx, by; };
     std::vector<It> its;
     size_t lds = 0;
     double flops = 0, bytes = 0;
@@ -165,9 +165,7 @@ int launch_wgrad_mega(const ssdn_wgrad_args* const* ops, int n, hipStream_t s) {
         for (int by = 0; by < p.gy; ++by)
             for (int bx = 0; bx < p.gx; ++bx) {
                 if (mb > 1 && (((bx >> 3) / mb) * 8 + (bx & 7)) >= ops[i]->nslabs) continue;       // (grid padding of the mblocks launch: no work)
-                // the mblocks blocks of one pixel partition stream the same tiles: keep them on one XCD (workgroup id mod 8), as in
-                // the op's own launch
-                its.push_back({c, i, bx, by, mb > 1 ? (bx & 7) : -1});
+                its.push_back({c, i, bx, by});
             }
     }
     // longest item first: blocks are dispatched in index order as CUs free up (stable: ties keep list order -- deterministic tables)
