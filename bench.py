@@ -388,7 +388,12 @@ def run_rank(args):
     # per-step metrics on the device, console / scalar logging at PRINT_INTERVAL.  Timed from step TR_WARM to the last step.
     trainer_value = trainer_info = None
     if world == 1 and not stub and not args.no_trainer_leg:
-        trainer_value, trainer_info = trainer_leg(B, P, max(200, args.steps), workers=args.trainer_workers)
+        try:
+            trainer_value, trainer_info = trainer_leg(B, P, max(200, args.steps), workers=args.trainer_workers)
+        except Exception as e:  # noqa: BLE001 -- a side leg must never cost the line its `value`
+            import traceback
+            traceback.print_exc()
+            trainer_value, trainer_info = None, {"error": "%s: %s" % (type(e).__name__, str(e)[:500])}
 
     if rank == 0:
         value = args.steps * B * world / dt
@@ -445,7 +450,7 @@ def run_rank(args):
             res["value_resident"] = resident_value
             res["value_with_fp32_h2d"] = fp32_value
             res["side_leg_steps"] = SIDE_STEPS
-        if trainer_value is not None:
+        if trainer_value is not None or trainer_info is not None:
             res["value_trainer_hdf5"] = trainer_value
             res["trainer_hdf5"] = trainer_info
         if world == 1 and not args.no_cpu_baseline and not stub:

@@ -23,6 +23,20 @@ static __device__ __forceinline__ void atomic_max_abs(uint32_t* gmax, float v) {
     for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_down(a, o, 64));
     if ((threadIdx.x & 63) == 0 && a > 0.f) atomicMax(gmax, __float_as_uint(a));
 }
+// ... one atomic per BLOCK (256 threads): the atomics of a launch all hit one address and serialise (~12 ns each); with one per wave a
+// launch of one pixel per thread spent more time in them than in its arithmetic
+static __device__ __forceinline__ void atomic_max_abs_block(uint32_t* gmax, float v, float* sh4) {
+    float a = fabsf(v);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a = fmaxf(a, __shfl_down(a, o, 64));
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float m = fmaxf(fmaxf(sh4[0], sh4[1]), fmaxf(sh4[2], sh4[3]));
+        if (m > 0.f) atomicMax(gmax, __float_as_uint(m));
+    }
+}
 static __device__ __forceinline__ float softplus_m4(float raw) {
     // torch.nn.Softplus(beta=1, threshold=20) applied to (raw - 4), + 1e-3   (denoiser.py:274-275)
     float x = raw - 4.f;
@@ -184,7 +198,7 @@ __global__ void k_head(ssdn_head_args a) {
         pp[0] = ls;
         pp[1] = gs * dest_draw * inv_total;
     }
-    if (a.want_grad && a.gmax) atomic_max_abs(a.gmax, gabs);
+    if (a.want_grad && a.gmax) atomic_max_abs_block(a.gmax, gabs, sh);
     if (blockIdx.x == 0 && threadIdx.x == 0 && a.noise_std && a.style == 0)
         a.noise_std[b] = a.mode == 0 ? fmaxf(npar, 1e-3f) : est;
 }

@@ -398,6 +398,10 @@ DEFER_TAIL = True
 # chain; leaving it where the bucket's last gradient appears makes two chains (3 + 9 ops) and starts it ~100 us earlier.
 CHAIN_POSTPONES = (2,)          # measured (tools/ab_lanes.py, same process): all buckets 1.975 ms per step, the encoder bucket only 1.959, none 1.965
 
+# Pixels of one sample a workgroup of the loss-head kernel walks (256 threads): 1024 = four pixels per thread in sequence.  (One pixel per
+# thread used to be slower, 33 vs 20 us, because every WAVE ended with an atomic on the gradient sentinel; the kernel now issues one per block.)
+HEAD_PX_PER_BLOCK = 1024
+
 # Lane of the chip-wide weight-gradient launches and their slab reductions (graph.WGRAD_MEGA).  A workgroup of those launches owns its
 # CU, one per CU: next to them nothing else runs, so they sit on the main lane (0), behind the data gradients whose results they read.
 MEGA_LANE = 0
@@ -437,7 +441,7 @@ class DenoiserEngine:
         self.noise_param = torch.zeros((B,), **f32)
         self.coords = torch.zeros((ncoords, 2), dtype=torch.int64, device=device)
         self.ncoords = ncoords
-        self.nchunks = max(1, min(64, (H * W) // 1024))     # (B x HW/256 workgroups measured slower: 33 vs 20 us)
+        self.nchunks = max(1, min(64, (H * W) // HEAD_PX_PER_BLOCK))
         self.partial = torch.zeros((B, self.nchunks, 2), **f32)
         self.est_raw = torch.zeros((B,), **f32)
         self.g_est_var = torch.zeros((B,), **f32)
