@@ -115,7 +115,7 @@ class DeviceNet:
         slab reductions (a run of reductions is two launches).  A group that would fall inside a run of chainable main-lane ops
         (k_conv_chain) waits behind the run.  Returns (records, layer name of each record if it is a reduction else None)."""
         side = lambda op: op.type in ("wgrad", "wreduce")   # noqa: E731
-        gof = lambda op: plan.wgrad_group_of(op.a["layer"])  # noqa: E731
+        gof = lambda op: plan.wgrad_group_of(op.a["layer"], plan.is_skip_half(op))  # noqa: E731
         flush = {}
         for i, op in enumerate(plan.bwd):
             if op.type == "wgrad":

@@ -635,16 +635,23 @@ class NetPlan:
             self._plan_mega()
 
     # ---- chip-wide weight-gradient launches ------------------------------------------------------------------
-    def wgrad_group_of(self, layer_name: str) -> int:
-        """index of the chip-wide launch the weight gradients of `layer_name` belong to (WGRAD_MEGA)"""
+    def wgrad_group_of(self, layer_name: str, skip_half: bool = False) -> int:
+        """index of the chip-wide launch the weight gradients of `layer_name` belong to (WGRAD_MEGA).  skip_half: the op covers the
+        skip-connection half of a decoder stage's first layer (its own SSDN_OP_WGRAD / SSDN_OP_WREDUCE pair: "<layer>/skip")."""
         if WGRAD_MEGA == "split":
-            return 0 if layer_name.startswith(SPLIT_GROUP0) else 1
+            return 0 if (layer_name + ("/skip" if skip_half else "/")).startswith(SPLIT_GROUP0) else 1
         if WGRAD_MEGA != "buckets":
             return 0
         off = {l.name: l.w_off for l in self.layers}
         a, b = off["decode_block_1.0"], off["decode_block_5.0"]        # (== ssdn.hip.dp.bucket_layers)
         w = off[layer_name]
         return 0 if w >= a else (1 if w >= b else 2)
+
+    @staticmethod
+    def is_skip_half(op) -> bool:
+        """the SSDN_OP_WGRAD / SSDN_OP_WREDUCE op of the skip-connection half of a decoder stage's first layer"""
+        return (op.type == "wgrad" and op.a.get("src0") is None and op.a["layer"].startswith("decode_block")) or \
+            (op.type == "wreduce" and op.a.get("c_off", 0) > 0 and not op.a.get("tapblock"))
 
     def wgrad_group_info(self, g: int):
         """(workgroups the launch of group g is planned for, lane, name of the layer whose DATA-GRADIENT launch it follows or None =
@@ -718,7 +725,7 @@ class NetPlan:
         allocate the slabs, and give every op its cost per block (the library packs the blocks onto the workgroups by it)."""
         groups: Dict[int, list] = {}
         for op, reds in self._mega_ops:
-            groups.setdefault(self.wgrad_group_of(op.a["layer"]), []).append((op, reds))
+            groups.setdefault(self.wgrad_group_of(op.a["layer"], self.is_skip_half(op)), []).append((op, reds))
         self.mega_makespan = {}
         for gi, members in sorted(groups.items()):
             W = self.wgrad_group_info(gi)[0]

@@ -13,7 +13,9 @@ from ssdn.params import NoiseAlgorithm
 dev = torch.device("cuda", 0)
 VARIANTS = {"per_layer_lanes": (None, 1), "mega_all_lane0": ("all", 0), "mega_split_half": ("split", 0, (1, 2)), "mega_split_3_8": ("split", 0, (3, 8)),
             "mega_split_5_8": ("split", 0, (5, 8)), "split_half_dec2": ("split", 0, (1, 2), ("output_block", "decode_block_2")),
-            "split_5_8_dec2": ("split", 0, (5, 8), ("output_block", "decode_block_2")), "split_half_dec22": ("split", 0, (1, 2), ("output_block", "decode_block_2.2")), "mega_buckets_lane0": ("buckets", 0), "mega_buckets_lane1": ("buckets", 1),
+            "split_5_8_dec2": ("split", 0, (5, 8), ("output_block", "decode_block_2")), "split_half_dec22": ("split", 0, (1, 2), ("output_block", "decode_block_2.2")),
+            "split_dec22_thin": ("split", 0, (1, 2), ("output_block", "decode_block_2.2", "decode_block_1.0/skip")),
+            "split_dec22_thin_d20s": ("split", 0, (1, 2), ("output_block", "decode_block_2.2", "decode_block_1.0/skip", "decode_block_2.0/skip")), "mega_buckets_lane0": ("buckets", 0), "mega_buckets_lane1": ("buckets", 1),
             "mega_all_lane1": ("all", 1)}
 if len(sys.argv) > 1:
     VARIANTS = {k: v for k, v in VARIANTS.items() if k in sys.argv[1:]}
