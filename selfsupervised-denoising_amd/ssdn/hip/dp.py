@@ -120,15 +120,32 @@ class GradExchange:
     def launch(self, flat_grad: torch.Tensor):
         if self.world <= 1 and not (self.force and dist.is_available() and dist.is_initialized()):
             return
-        for k, (lo, hi) in enumerate(self.ranges):
-            if hi <= lo:
-                continue
+        for lo, hi, ks in self._units():
             if self.comm_stream is not None:
-                self.comm_stream.wait_event(self.events[k])
+                for k in ks:
+                    self.comm_stream.wait_event(self.events[k])
                 with torch.cuda.stream(self.comm_stream):
                     self.pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
             else:
                 self.pending.append(dist.all_reduce(flat_grad[lo:hi], op=dist.ReduceOp.SUM, async_op=True))
+
+    def _units(self):
+        """(lo, hi, bucket indexes) of the collectives to issue.  `groups` (set by the engine that builds the event-carrying backward
+        list) names buckets whose completion marks sit at the SAME point of the list -- with the chip-wide weight-gradient launch
+        every main-net bucket completes behind the final reduction run -- : such buckets are exchanged as ONE all-reduce when their
+        ranges are adjacent in the flat buffer (one latency-bound ring instead of three back to back)."""
+        groups = getattr(self, "groups", None) or [[k] for k in range(len(self.ranges))]
+        units = []
+        for g in groups:
+            ks = sorted((k for k in g if self.ranges[k][1] > self.ranges[k][0]), key=lambda k: self.ranges[k][0])
+            if not ks:
+                continue
+            contiguous = all(self.ranges[a][1] == self.ranges[b][0] for a, b in zip(ks, ks[1:]))
+            if contiguous:
+                units.append((self.ranges[ks[0]][0], self.ranges[ks[-1]][1], ks))
+            else:
+                units += [(self.ranges[k][0], self.ranges[k][1], [k]) for k in ks]
+        return units
 
     def finish(self) -> float:
         for w in self.pending:

@@ -94,10 +94,17 @@ class DeviceNet:
             for k, b in enumerate(buckets):
                 if name in b:
                     last[k] = i
+        # (a mark inside a run of consecutive reductions would split the run -- the executor merges a run into two launches --: it moves
+        #  to the end of the run; buckets that end in the same run are then marked at the same point)
+        for k in list(last):
+            i = last[k]
+            while i + 1 < len(self._bwd_recs) and self._bwd_recs[i + 1][0] == "wreduce":
+                i += 1
+            last[k] = i
         recs = []
         for i, r in enumerate(self._bwd_recs):
             recs.append(r)
-            for k, idx in last.items():
+            for k, idx in sorted(last.items()):
                 if idx == i:
                     recs.append(("event_record", L.EventArgs(events[k])))
         ol = OpList.__new__(OpList)
@@ -105,6 +112,11 @@ class DeviceNet:
         for j, r in enumerate(recs):                       # the record rides the lane of the reduction it follows
             if r[0] == "event_record":
                 ol.arr[j].lane = ol.arr[j - 1].lane if j > 0 else 0
+        # buckets whose marks sit at the same point of the list complete together: the exchange may merge their collectives
+        by_pos = {}
+        for k, idx in last.items():
+            by_pos.setdefault(idx, []).append(k)
+        ol.coincident = [sorted(ks) for _, ks in sorted(by_pos.items())]
         return ol
 
     @staticmethod
@@ -578,6 +590,7 @@ class DenoiserEngine:
             if getattr(self, "_bwd_ev_key", None) != id(exchange):
                 self._bwd_ev = self.main.bwd_with_events(bucket_layers(self.main.plan.layers), exchange.event_handles()[:3])
                 self._bwd_ev_key = id(exchange)
+                exchange.groups = [list(g) for g in self._bwd_ev.coincident] + [[k] for k in range(3, len(exchange.ranges))]
             self._bwd_ev.run(s)
             if self.sigma is not None:
                 self.sigma.bwd.run(s)

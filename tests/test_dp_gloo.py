@@ -157,3 +157,27 @@ def test_gradient_buckets_of_the_benchmark_network():
     off = {l.name: l.w_off for l in layers}
     for k, b in enumerate(names):                                          # a bucket's layers are exactly its range of the buffer
         assert all(r[k][0] <= off[n] < r[k][1] for n in b)
+
+
+def test_coincident_buckets_are_exchanged_as_one_collective():
+    """With the chip-wide weight-gradient launch every main-net bucket completes behind the final reduction run: the engine reports the
+    buckets as coincident (`GradExchange.groups`) and adjacent ranges become ONE all-reduce; non-adjacent or separate buckets stay."""
+    ex = dp.GradExchange(2, [(60, 100), (20, 60), (0, 20), (100, 130)], torch.device("cpu"))
+    assert [(lo, hi) for lo, hi, _ in ex._units()] == [(60, 100), (20, 60), (0, 20), (100, 130)]
+    ex.groups = [[0, 1, 2], [3]]
+    assert [(lo, hi, ks) for lo, hi, ks in ex._units()] == [(0, 100, [2, 1, 0]), (100, 130, [3])]
+    ex.groups = [[0, 2], [1], [3]]                      # (not adjacent: not merged)
+    assert [(lo, hi) for lo, hi, _ in ex._units()] == [(0, 20), (60, 100), (20, 60), (100, 130)]
+    # the engine side: marks of buckets that end in one run of reductions sit behind that run, at the same point
+    from ssdn.hip.engine import DeviceNet
+    from ssdn.hip.graph import NetPlan
+    from ssdn.hip import lib as L
+    plan = NetPlan("m/", 3, 9, True, 32, 64, 64, cus=256)
+    flat = torch.zeros(plan.nparams)
+    dn = DeviceNet(plan, torch.device("cpu"), flat, torch.zeros_like(flat))
+    ol = dn.bwd_with_events(dp.bucket_layers(plan.layers), [11, 22, 33])
+    types = [int(ol.arr[i].type) for i in range(ol.n)]
+    ev, red = L.OP["event_record"], L.OP["wreduce"]
+    assert types[-3:] == [ev, ev, ev] and types[-4] == red and ol.coincident == [[0, 1, 2]]
+    runs = sum(1 for i, t in enumerate(types) if t == red and (i == 0 or types[i - 1] != red))
+    assert runs == 2, "reductions: the side group's run and the final run, not split by the marks"
