@@ -101,6 +101,8 @@ struct WgAux {
     unsigned mg_ccx, mg_ccd;  // their magic reciprocals (per-lane: piece of a row -> pixel, chunk)
     unsigned mg_hh;           // scalar: halo row -> (image of the tile, halo y)
     int rswx, rswd;           // rows of the input halo image / of the dZ image each wave stages per tile
+    int sync;                 // 1: the tiles cannot be prefetched within their K-steps (images of 4x4 pixels and below: many short rows):
+                              // every tile is fetched synchronously into image 0 before its K-steps -- a workgroup may still own several
 };
 
 #define WG_ND 3                             // 64-lane loads per dZ row (<= 16 pixels x 12 chunks)
@@ -303,10 +305,11 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
     constexpr int NPV = BOTH ? NL + WG_ND : (NL > WG_ND ? NL : WG_ND);
     const int nit = BOTH ? (x.rswx > x.rswd ? x.rswx : x.rswd) : x.rswx + x.rswd;   // row items per wave per tile
 
-    if (ntl > 0) {   // first image: synchronous, PB row items in flight
-        constexpr int PB = BOTH ? 3 : 6;
+    // synchronous fetch of tile ti into image 0, PB row items in flight (the first tile of every workgroup; every tile in sync mode)
+    auto sync_load = [&](int ti, auto PBc) __attribute__((always_inline)) {
+        constexpr int PB = decltype(PBc)::value;
         int n0, y0, x0;
-        origin(0, n0, y0, x0);
+        origin(ti, n0, y0, x0);
         for (int r0 = 0; r0 < nit; r0 += PB) {
             half8 tv[PB][NPV];
             int tl[PB], td[PB];
@@ -339,7 +342,8 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
                 }
             }
         }
-    }
+    };
+    if (ntl > 0) sync_load(0, std::integral_constant<int, (BOTH ? 3 : 6)>{});
     __syncthreads();
     stamp();
 
@@ -376,11 +380,20 @@ static __device__ __forceinline__ void wgrad_body(const ssdn_wgrad_args& a, cons
 #pragma unroll
     for (int r = 0; r < 2; ++r) xl_first[r] = first_bias ? lane * 8 : xlane[r] + mh * 32;
 
+    // (sync mode only exists for the run-time-staged variants with at most 16 accumulators: the fetch's registers next to 21 would spill)
+    constexpr bool CAN_SYNC = KS == 0 && MT * CPW <= 16;
+    const bool syncm = CAN_SYNC && x.sync != 0;
     for (int i = 0; i < ntl; ++i) {
-        const char* xt_c = smem + (i & 1) * bufsz;
+        if constexpr (CAN_SYNC) {
+            if (syncm && i > 0) {
+                sync_load(i, std::integral_constant<int, 2>{});
+                __syncthreads();
+            }
+        }
+        const char* xt_c = smem + (syncm ? 0 : (i & 1)) * bufsz;
         const char* dt_c = xt_c + g.XB;
         char* img_n = smem + ((i + 1) & 1) * bufsz;
-        const bool more = i + 1 < ntl;   // the last tile prefetches nothing
+        const bool more = !syncm && i + 1 < ntl;   // the last tile prefetches nothing
         int n0 = 0, y0 = 0, x0 = 0;
         if (more) origin(i + 1, n0, y0, x0);
 
@@ -687,7 +700,7 @@ static int wgrad_validate(const ssdn_wgrad_args* a) {
 //   nl = 4, both = 0: one row item per K-step (input rows, then dZ rows), <= 4 loads per input row
 //   nl = 6, both = 1: one input row AND one dZ row per K-step, <= 6 loads per input row
 // nl = 99: the tile cannot be prefetched.
-struct WgItems { int rswx, rswd, nl, both; };
+struct WgItems { int rswx, rswd, nl, both, sync; };
 static WgItems wgrad_items(const ssdn_wgrad_args* a, const WgGeom& g) {
     WgItems t;
     const int npix = g.TN * g.TH * g.TW;
@@ -696,10 +709,11 @@ static WgItems wgrad_items(const ssdn_wgrad_args* a, const WgGeom& g) {
     t.rswd = (g.TN * g.TH + WG_WAVES - 1) / WG_WAVES;
     const int steps = (npix >> 4) - 2;             // loads are issued in K-steps 0..ksteps-3
     const bool single = g.ntiles <= a->nslabs;     // one tile per workgroup: nothing to prefetch
-    t.nl = 99; t.both = 0;
+    t.nl = 99; t.both = 0; t.sync = 0;
     if (id > WG_ND) return t;
     if (ix <= 4 && (single || t.rswx + t.rswd <= steps)) { t.nl = 4; t.both = 0; }
     else if (ix <= 6 && (single || (t.rswx <= steps && t.rswd <= steps))) { t.nl = 6; t.both = 1; }
+    else if (ix <= 6) { t.nl = ix <= 4 ? 4 : 6; t.both = ix <= 4 ? 0 : 1; t.sync = 1; }   // several tiles per workgroup, none prefetched
     return t;
 }
 // the compile-time schedules of the layers with <= 48 input channels (an input row = 18 pixels x 6 pieces = 108 pieces) take TWO 64-lane
@@ -724,6 +738,7 @@ static int wgrad_prepare(const ssdn_wgrad_args* a, WgPrep* p) {
     p->wi = wgrad_items(a, p->g);
     if (p->wi.nl > 6) return ssdn_set_error("wgrad: the tile cannot be prefetched within its K-steps (too many rows / too wide rows)");
     x.rswx = p->wi.rswx; x.rswd = p->wi.rswd;
+    x.sync = p->wi.sync;
     p->MT = a->Mpad / 32;
     const int CT = a->ntaps * (a->Kpad / 32) + 1;
     p->gy = a->csplit > 1 ? a->csplit : 1;
@@ -731,6 +746,8 @@ static int wgrad_prepare(const ssdn_wgrad_args* a, WgPrep* p) {
     p->gx = a->mblocks > 1 ? ((a->nslabs + 7) / 8) * 8 * a->mblocks : a->nslabs;
     p->lds = 2 * ((size_t)p->g.XB + (size_t)p->g.DB) + WG_ONES_BYTES;
     if (p->lds > 160 * 1024) return ssdn_set_error("wgrad: tiling needs %zu B of LDS (> 160 KiB)", p->lds);
+    if (p->wi.sync && p->MT * p->CPW > 16)
+        return ssdn_set_error("wgrad: the tile cannot be prefetched within its K-steps and the %d-accumulator variant has no synchronous mode (use column groups)", p->MT * p->CPW);
     return 0;
 }
 

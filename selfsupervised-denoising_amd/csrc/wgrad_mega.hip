@@ -78,10 +78,10 @@ static WgVariant wgrad_variant(const ssdn_wgrad_args* a, const WgPrep& p) {
     const WgGeom& g = p.g;
     const WgItems& wi = p.wi;
     const int ksteps = (g.TN * g.TH * g.TW) >> 4;
-    const bool st = !wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs;
+    const bool st = !wi.both && !wi.sync && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs;
     const bool st8 = st && g.PSTR == 192 && ksteps == 8 && wi.rswx == 3 && wi.rswd == 2;
     const bool st16 = st && g.PSTR == 64 && ksteps == 16 && wi.rswx == 5 && wi.rswd == 4;
-    const bool st4b = wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
+    const bool st4b = wi.both && !wi.sync && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
     v.nl = wi.both ? 6 : 4; v.both = wi.both ? 1 : 0;
     if (st4b && v.mt == 3 && v.cpw == 4) { v.ps = 832; v.ks = 4; v.rwx = 2; v.rwd = 2; }
     else if (wi.both) {}

@@ -217,11 +217,11 @@ int launch_wgrad(const ssdn_wgrad_args* a, hipStream_t s) {
     //   3x3, 48..96 input channels: stride 192 B, 16x8 tiles  -> 8 K-steps, 3 input + 2 dZ rows per wave
     //   3x3, 16..32 input channels: stride  64 B, 16x16 tiles -> 16 K-steps, 5 + 4 rows per wave
     const int ksteps = (g.TN * g.TH * g.TW) >> 4;
-    const bool st = !wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs;
+    const bool st = !wi.both && !wi.sync && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs;
     const bool st8 = st && g.PSTR == 192 && ksteps == 8 && wi.rswx == 3 && wi.rswd == 2;
     const bool st16 = st && g.PSTR == 64 && ksteps == 16 && wi.rswx == 5 && wi.rswd == 4;
     // 1x1 layers over four 96-channel input blocks: stride 832 B, 8x8 tiles -> 4 K-steps, an input row AND a dZ row per K-step
-    const bool st4b = wi.both && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
+    const bool st4b = wi.both && !wi.sync && a->ltn == 0 && a->ltw >= 3 && g.ntiles > a->nslabs && g.PSTR == 832 && ksteps == 4 && wi.rswx == 2 && wi.rswd == 2;
     // (a static variant is only instantiated for the (mt, cpw) it is used with: elsewhere its template arguments collapse to
     //  the generic kernel's)
     if (st8 && wgrad_nl2(a, g, MT, CPW)) {

@@ -44,6 +44,7 @@ MEGA_COST = {
     "head": (1208.0, 0.0),        # 1x1 layers over four 96-channel input blocks (an input AND a dZ row per K-step)
     "head_mb": (1208.0, 0.0),     # ... with the 4 output blocks of a pixel partition side by side (input shared through L2)
     "thin": (2211.0, 963.0),      # k_wgrad_thin: per 256-pixel tile: base + per 32 output channels
+    "sync_tile": 9000.0,          # a tile fetched synchronously (unprefetchable tiles of the 4x4 / 2x2 layers), on top of its K-steps
     "fixed": 30000.0,             # prologue (first tile fetched synchronously), launch ramp
     "slab_rate": 10.0,            # bytes per cycle a workgroup writes its slab with
 }
@@ -693,12 +694,15 @@ class NetPlan:
             return (4, 4, 0), ntiles, C_["thin"][0] + C_["thin"][1] * MT, fixed
         ctiles = ntaps * Kpad // 32 + 1
         cpw = -(-ctiles // 4)
+        sync = False
         try:
             tile, ntiles = choose_wgrad_tile(N, H, W, a["taps"], max(Kpad, a["Ktot"]), Mpad, a["Ktot"], a["M"], 1)
         except ValueError:
-            # no tile the kernel could prefetch while another is on the matrix cores: one tile per workgroup (`min_ns`)
-            tile, ntiles = choose_wgrad_tile(N, H, W, a["taps"], max(Kpad, a["Ktot"]), Mpad, a["Ktot"], a["M"], self.cus)
-            a["_min_ns"] = ntiles
+            # no tile the kernel could prefetch while another is on the matrix cores (images of 4x4 pixels and below: many short
+            # rows): the workgroup fetches every tile synchronously (csrc/wgrad_body.h, WgAux.sync) -- still several tiles per
+            # workgroup, i.e. one slab per workgroup instead of one per tile
+            tile, ntiles = choose_wgrad_tile(N, H, W, a["taps"], max(Kpad, a["Ktot"]), Mpad, a["Ktot"], a["M"], 1 << 30)
+            sync = True
         ltw, lth, ltn = tile
         ksteps = (1 << sum(tile)) // 16
         HW_ = (1 << ltw) + (max(t[1] for t in a["taps"]) - min(t[1] for t in a["taps"]))
@@ -718,7 +722,7 @@ class NetPlan:
         cpw = -(-ctiles // (4 * G))
         base, per = C_[kind]
         fixed = C_["fixed"] + slab_bytes / C_["slab_rate"] / G
-        return tile, ntiles, ksteps * (base + per * MT * cpw), fixed
+        return tile, ntiles, ksteps * (base + per * MT * cpw) + (C_["sync_tile"] if sync else 0.0), fixed
 
     def _plan_mega(self):
         """Size the grid of every weight-gradient op so that the workgroups of its chip-wide launch (one per CU) finish together,
@@ -743,7 +747,6 @@ class NetPlan:
                 for c in cand:
                     ns = -(-int(c["ntiles"] * c["c_tile"]) // max(1, int(t - c["fixed"])))
                     ns = max(1, min(c["ntiles"], ns, max(1, W // c["mb"])))
-                    ns = max(ns, c["op"].a.get("_min_ns", 1))
                     res.append((ns, -(-c["ntiles"] // ns) * c["c_tile"] + c["fixed"]))
                 return res
 

@@ -101,6 +101,8 @@ def trace():
         if t.dtype in (torch.float16, torch.bfloat16):
             t.copy_(torch.randn(t.shape, device=dev) * 0.5)
     ops = [op for op in plan.bwd if op.type == "wgrad"]
+    if G.WGRAD_MEGA == "split":          # the production plan: trace the chip-wide launch (group 1) alone
+        ops = [op for op in ops if plan.wgrad_group_of(op.a["layer"], plan.is_skip_half(op)) == 1]
     ol = OpList([dn._mat(op) for op in ops])
     for _ in range(3):
         ol.run(current_stream())
@@ -159,7 +161,7 @@ def load():
         seen.add(key)
         mb, G = max(1, a["mblocks"]), max(1, a["csplit"])
         for ns in sorted({min(ntiles, cus // (mb * G)), min(ntiles, cus // (2 * mb * G))}, reverse=True):
-            if ns < max(1, a.get("_min_ns", 1)):
+            if False:
                 continue
             a2 = dict(a)
             a2["nslabs"] = ns
