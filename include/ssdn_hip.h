@@ -35,7 +35,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SSDN_ABI_VERSION 9
+#define SSDN_ABI_VERSION 10
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -163,6 +163,9 @@ typedef struct ssdn_conv_args {
      * needs bf16 = 1, a 1x1 layer with M = 384, H == W a power of two, no mask / add (ssdn_conv_fuses_unrot()). */
     ssdn_view unrot;
     ssdn_view unrot_mask;
+    /* optional: the sign bytes SSDN_OP_UNROT_FWD wrote for unrot_mask's tensor (ssdn_unrot_args.smask); when set they are read
+     * instead of unrot_mask (same result: only the sign of the activation enters LeakyReLU'). */
+    const void* unrot_smask;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -199,6 +202,10 @@ typedef struct ssdn_unrot_args {
     ssdn_view dst;  /* FWD: [B,P,P,4C] ; BWD: [4B,P,P,C] */
     ssdn_view mask; /* BWD only: [4B,P,P,C] saved activation */
     int32_t B, P, C;
+    /* FWD, optional: [4B,P,P,C/8] bytes, bit q of byte k = (src channel 8k+q > 0) -- the LeakyReLU sign of every pixel the
+     * un-rotation reads (rows y <= P-2; row P-1 is cut off by the shift and left untouched).  The fused backward
+     * (ssdn_conv_args.unrot_smask) reads these 12 bytes per pixel instead of the 192-byte activation. */
+    void* smask;
 } ssdn_unrot_args;
 
 /* ---- SSDN_OP_WGRAD --------------------------------------------------------------------------

@@ -119,7 +119,7 @@ class Interp:
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
                 ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-                unrot=None, unrot_mask=None):
+                unrot=None, unrot_mask=None, unrot_smask=None):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -144,7 +144,12 @@ class Interp:
             for r, ang in enumerate((0, 90, 180, 270)):
                 gs = self._rot(g[..., r * C4:(r + 1) * C4], ang)
                 outs.append(torch.cat([gs[:, 1:], torch.zeros(N, 1, W, C4)], 1))
-            self.store(unrot, C4, torch.cat(outs, 0) * _lgrad(self.view(unrot_mask, C4)))
+            if unrot_smask is not None:      # the sign bytes SSDN_OP_UNROT_FWD left (rows y <= P-2; row P-1 only meets zeros)
+                bits = (self.t[unrot_smask].to(torch.int64)[..., None] >> torch.arange(8)) & 1
+                lg = torch.where(bits.reshape(*bits.shape[:3], -1)[..., :C4] > 0, 1.0, LRELU)
+            else:
+                lg = _lgrad(self.view(unrot_mask, C4))
+            self.store(unrot, C4, torch.cat(outs, 0) * lg)
             return
         if upsum is not None:      # fused SSDN_OP_UPSUM_BWD of the (rounded) channels below upsum_c; the rest goes to dst
             r = _r16(out[..., :upsum_c], self.fp16, self.plan.tensors[dst.t].kind)
@@ -194,8 +199,11 @@ class Interp:
             return x.flip(2).flip(1)
         return x.flip(1).transpose(1, 2)
 
-    def op_unrot_fwd(self, src, dst, B, P, C):
+    def op_unrot_fwd(self, src, dst, B, P, C, smask=None):
         y = self.view(src, C)
+        if smask is not None:     # bit q of byte k = (channel 8k+q > 0)
+            pos = (y > 0).to(torch.int64).reshape(4 * B, P, P, C // 8, 8)
+            self.t[smask] = (pos << torch.arange(8)).sum(-1).to(torch.uint8)
         s = torch.cat([torch.zeros(4 * B, 1, P, C), y[:, :-1]], 1)
         parts = [self._rot(s[r * B:(r + 1) * B], a) for r, a in enumerate((0, 270, 180, 90))]
         self.store(dst, 4 * C, torch.cat(parts, -1))

@@ -210,8 +210,16 @@ __global__ void k_unrot_fwd(ssdn_unrot_args a) {
         default: u = j; v = P - 1 - i; break;
     }
     half8 val = zero_h8();
-    if (u >= 1)
-        val = ld_h8((const h16*)a.src.p + a.src.co + c + ((((long long)r * a.B + b) * P + (u - 1)) * P + v) * a.src.cs);
+    if (u >= 1) {
+        const long long spix = (((long long)r * a.B + b) * P + (u - 1)) * P + v;
+        val = ld_h8((const h16*)a.src.p + a.src.co + c + spix * a.src.cs);
+        if (a.smask) {                                   // every source pixel with y <= P-2 is read exactly once: its sign byte
+            unsigned m = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) m |= ((float)val[q] > 0.f ? 1u : 0u) << q;
+            ((unsigned char*)a.smask)[spix * C8 + (c >> 3)] = (unsigned char)m;
+        }
+    }
     st_h8((h16*)a.dst.p + a.dst.co + r * a.C + c + (long long)p * a.dst.cs, val);
 }
 int launch_unrot_fwd(const ssdn_unrot_args* a, hipStream_t s) {

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     constexpr int EG = gd_eg(WM), NEG = WM / EG;             // epilogue: channel tiles per transpose group
     constexpr int OSTR = EG * 64 + 16, NEK = EG * 2, CPP = EG * 4;
     constexpr int BOFF = DA * ABYTES, EOFF = BOFF + DB * BBYTES, BIAS_OFF = EOFF + NW * 32 * OSTR, DUMMY_OFF = BIAS_OFF + TM * 4;
-    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0, OUT4 = (EPI & 4) != 0;
+    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0, OUT4 = (EPI & 4) != 0, SMASK = (EPI & 8) != 0;
     static_assert(!OUT4 || (NWM == 1 && WM == 3 && gd_eg(WM) == 3 && !BF), "the fused narrow layer needs the wave's whole 96-channel tile in its LDS region");
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,6 +92,7 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_um = __builtin_amdgcn_make_buffer_rsrc(a.unrot_mask.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_us = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.unrot_smask), 0, SMASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
 
     // DMA lane constants: lane -> (row lane >> 2 of a 16-row instruction, LDS piece lane & 3); the piece fetched is the swizzled one
     const int drow = lane >> 2, dpiece = (lane & 3) ^ ((drow >> 2) & 3);
@@ -268,7 +269,10 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                         live[k] = u >= 1;                                  // u == 0: the shift cut it off -> zero row y = P-1
                         const int dpix = (((((r * a.N + b) << lp) + (u >= 1 ? u - 1 : P - 1))) << lp) + v;
                         goff[k] = (dpix * a.unrot.cs + a.unrot.co + cc) * 2;
-                        mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
+                        if constexpr (SMASK)      // one sign byte per 16-byte piece (written by SSDN_OP_UNROT_FWD), 12 bytes per pixel
+                            mb[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_us, live[k] ? dpix * 12 + (cc >> 3) : (int)0x80000000, 0, 0);
+                        else
+                            mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
                     } else {
                         goff[k] = (pix * a.dst.cs + a.dst.co + chb) * 2 + c16;
                         if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + chb) * 2 + c16, 0, 0);
@@ -286,9 +290,11 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                             float v0, v1;
                             if constexpr (BF) { v0 = bf_lo(o[q]); v1 = bf_hi(o[q]); }
                             else { v0 = f16_lo(o[q]); v1 = f16_hi(o[q]); }
-                            const int mlo = (int)(short)(mb[k][q] & 0xffffu), mhi = (int)mb[k][q] >> 16;
-                            v0 *= mlo > 0 ? 1.f : LRELU_SLOPE;
-                            v1 *= mhi > 0 ? 1.f : LRELU_SLOPE;
+                            bool p0, p1;
+                            if constexpr (SMASK) { p0 = (mb[k][0] >> (2 * q)) & 1u; p1 = (mb[k][0] >> (2 * q + 1)) & 1u; }
+                            else { p0 = (int)(short)(mb[k][q] & 0xffffu) > 0; p1 = ((int)mb[k][q] >> 16) > 0; }
+                            v0 *= p0 ? 1.f : LRELU_SLOPE;
+                            v1 *= p1 ? 1.f : LRELU_SLOPE;
                             o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
                         }
                     }
@@ -356,7 +362,7 @@ static int gd_launch(const ssdn_conv_args* a, hipStream_t s, const ssdn_conv_arg
 
 int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s) {
     const int epi = a->mask.p ? 1 : 0;
-    if (a->unrot.p) return gd_launch<2, 6, 4, 2, true, 2>(a, s);
+    if (a->unrot.p) return a->unrot_smask ? gd_launch<2, 6, 4, 2, true, 10>(a, s) : gd_launch<2, 6, 4, 2, true, 2>(a, s);
     if (a->Mpad == 384) {
         if (!a->bf16) return gd_launch<2, 6, 4, 2, false, 0>(a, s);
         return epi ? gd_launch<2, 6, 4, 2, true, 1>(a, s) : gd_launch<2, 6, 4, 2, true, 0>(a, s);

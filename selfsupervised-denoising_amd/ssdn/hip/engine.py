@@ -57,7 +57,7 @@ class DeviceNet:
     """One NoiseNetwork instance on the device for a fixed input shape: buffers + materialised fwd/bwd/pack op lists."""
 
     DT = {"act": torch.float16, "actb": torch.bfloat16, "f16": torch.float16, "bf16": torch.bfloat16, "f32": torch.float32,
-          "u32": torch.int32, "i64": torch.int64}
+          "u32": torch.int32, "i64": torch.int64, "u8": torch.uint8}
 
     def __init__(self, plan: NetPlan, device, params: torch.Tensor, grads: Optional[torch.Tensor],
                  shared: Optional[Dict[str, torch.Tensor]] = None):
@@ -339,6 +339,7 @@ class DeviceNet:
             if a.get("upsum") is not None and not L.load().ssdn_conv_fuses_upsum(C.byref(s)):
                 raise L.SsdnHipError("conv %s: the plan fuses UPSUM_BWD but the library cannot (planner / library rule mismatch)" % a["layer"])
             s.unrot, s.unrot_mask = self._view(a.get("unrot")), self._view(a.get("unrot_mask"))
+            s.unrot_smask = self.t[a["unrot_smask"]].data_ptr() if a.get("unrot_smask") else None
             if a.get("unrot") is not None and not L.load().ssdn_conv_fuses_unrot(C.byref(s)):
                 raise L.SsdnHipError("conv %s: the plan fuses UNROT_BWD but the library cannot (planner / library rule mismatch)" % a["layer"])
             if L.load().ssdn_conv_lds_bytes(C.byref(s)) < 0:
@@ -350,7 +351,8 @@ class DeviceNet:
         if op.type == "upsum_bwd":
             return op.type, L.UpsumArgs(self._view(a["src"]), self._view(a["mask"]), self._view(a["dst"]), a["N"], a["H"], a["W"], a["C"])
         if op.type in ("unrot_fwd", "unrot_bwd"):
-            return op.type, L.UnrotArgs(self._view(a["src"]), self._view(a["dst"]), self._view(a.get("mask")), a["B"], a["P"], a["C"])
+            return op.type, L.UnrotArgs(self._view(a["src"]), self._view(a["dst"]), self._view(a.get("mask")), a["B"], a["P"], a["C"],
+                                        self.t[a["smask"]].data_ptr() if a.get("smask") else None)
         if op.type == "wgrad":
             s = L.WgradArgs()
             s.dz, s.src0, s.src1 = self._view(a["dz"]), self._view(a["src0"]), self._view(a["src1"])

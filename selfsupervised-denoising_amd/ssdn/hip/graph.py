@@ -29,6 +29,7 @@ WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient 
 #   "all": one launch behind the last data gradient; "buckets": one per gradient bucket (ssdn.hip.dp.bucket_layers);
 #   None: round 3's per-layer launches on the side lane
 WGRAD_MEGA = "split"
+SIGN_BYTES = True             # the fused un-rotation of the backward pass reads LeakyReLU sign bytes (12 B/pixel) instead of d1b (192 B/pixel)
 MEGA_MIN_PX = 32768           # networks with fewer pixels (N*H*W) at full resolution keep the per-layer launches: a handful of tiles per
                               # layer is latency, not throughput (config 1's shape, batch 4 at 32x32: 0.66 ms per step vs 0.70 / 0.77)
 SPLIT_HEAD_CUS = (1, 2)       # "split": share of the CUs the side-lane launch is planned for
@@ -322,7 +323,7 @@ class NetPlan:
 
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
               bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-              unrot=None, unrot_mask=None):
+              unrot=None, unrot_mask=None, unrot_smask=None):
         """pool: view of the pooled tensor -- the conv's epilogue also writes Shift2d + MaxPool2d(2) of its output
         (ssdn_conv_args.pool).  Returns True if the pool was fused (the caller then emits no SSDN_OP_POOL_FWD)."""
         Ktot = c0 + c1
@@ -344,7 +345,7 @@ class NetPlan:
                                    pool=pool if (fused and pool is not None) else None,
                                    pool_shifted=int(pool_shifted) if (fused and pool is not None) else 0,
                                    upsum=upsum, upsum_mask=upsum_mask, upsum_c=int(upsum_c) if upsum is not None else 0,
-                                   unrot=unrot, unrot_mask=unrot_mask)))
+                                   unrot=unrot, unrot_mask=unrot_mask, unrot_smask=unrot_smask)))
         return fused
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
@@ -515,7 +516,10 @@ class NetPlan:
         nin = 384 if bs else 96
         if bs:
             u = self.act("u", B, H, W, 384)
-            f.append(Op("unrot_fwd", dict(src=View(d1b), dst=View(u), B=B, P=H, C=96)))
+            # with training: one LeakyReLU sign byte per 8 channels of d1b, for the fused un-rotation of the backward pass
+            fused_unrot = H == W and H & (H - 1) == 0 and (B * H * W) % 256 == 0
+            smk = self.T("smk_d1b", "u8", (N, H, W, 96 // 8)) if (self.train and SIGN_BYTES and fused_unrot) else None
+            f.append(Op("unrot_fwd", dict(src=View(d1b), dst=View(u), B=B, P=H, C=96, smask=smk)))
             head_in = u
         else:
             head_in = d1b
@@ -579,10 +583,11 @@ class NetPlan:
         lo0 = L["output_block.0"]
         self._wgrad(lo0, View(g_na), 96, View(head_in), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, cblocks=blocks, mblocks=nin // 96)
         g_d1b = self.grad("g_d1b", N, H, W, 96)
-        if bs and H == W and H & (H - 1) == 0 and (B * H * W) % 256 == 0:
+        if bs and fused_unrot:
             # the data-gradient GEMM scatters its four 96-channel blocks straight into the rotated tensors (fused
             # SSDN_OP_UNROT_BWD, k_gdma; the library's rule: csrc/gemm_dma.hip::gemm_dma_eligible)
-            dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, None, unrot=View(g_d1b), unrot_mask=View(d1b))
+            dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, None, unrot=View(g_d1b), unrot_mask=View(d1b),
+                  unrot_smask=smk)
         elif bs:
             g_u = self.grad("g_u", B, H, W, 384)
             dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, View(g_u))

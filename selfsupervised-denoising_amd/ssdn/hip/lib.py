@@ -38,7 +38,7 @@ class ConvArgs(C.Structure):
                 ("Ktot", i32), ("bias", vp), ("act", i32), ("mask", View), ("add", View), ("dst", View), ("dst32", vp),
                 ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32), ("bf16", i32), ("wc", vp), ("kreal", i32),
                 ("pool", View), ("pool_shifted", i32), ("upsum", View), ("upsum_mask", View), ("upsum_c", i32),
-                ("unrot", View), ("unrot_mask", View)]
+                ("unrot", View), ("unrot_mask", View), ("unrot_smask", vp)]
 
 
 class PoolArgs(C.Structure):
@@ -51,7 +51,7 @@ class UpsumArgs(C.Structure):
 
 
 class UnrotArgs(C.Structure):
-    _fields_ = [("src", View), ("dst", View), ("mask", View), ("B", i32), ("P", i32), ("C", i32)]
+    _fields_ = [("src", View), ("dst", View), ("mask", View), ("B", i32), ("P", i32), ("C", i32), ("smask", vp)]
 
 
 class WgradArgs(C.Structure):
@@ -127,7 +127,7 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
                  mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, metrics=MetricsArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 9      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 10      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",

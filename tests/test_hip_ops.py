@@ -216,8 +216,19 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
         pv = op.a.get("pool") if op.type == "conv" else None
         if pv is not None:
             dn.t[pv.t][..., pv.co:pv.co + ch] = float("nan")
+        smk = op.a.get("smask") if op.type == "unrot_fwd" else None
+        if smk is not None:
+            dn.t[smk].fill_(0xA5)
         OpList([rec]).run(current_stream())
         torch.cuda.synchronize()
+        if smk is not None:
+            # LeakyReLU sign bytes of the un-rotated tensor: exact (the input is the forced one); row P-1 is not the kernel's to write
+            gots, wants = dn.t[smk].cpu(), it.t[smk]
+            if not torch.equal(gots[:, :-1], wants[:, :-1]):
+                failures.append("op %d unrot_fwd: %d sign bytes differ" % (i, int((gots[:, :-1] != wants[:, :-1]).sum())))
+            if not bool((gots[:, -1] == 0xA5).all()):
+                failures.append("op %d unrot_fwd: sign bytes of the cut-off row were written" % i)
+            dn.t[smk].copy_(wants)
         if pv is not None:
             # fused max-pool: exactly SSDN_OP_POOL_FWD of what the launch itself stored (max is exact on the rounded values)
             mine = dn.t[dst.t][..., dst.co:dst.co + ch].float().cpu()
