@@ -35,7 +35,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SSDN_ABI_VERSION 10
+#define SSDN_ABI_VERSION 11
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -166,6 +166,14 @@ typedef struct ssdn_conv_args {
     /* optional: the sign bytes SSDN_OP_UNROT_FWD wrote for unrot_mask's tensor (ssdn_unrot_args.smask); when set they are read
      * instead of unrot_mask (same result: only the sign of the activation enters LeakyReLU'). */
     const void* unrot_smask;
+    /* fused SSDN_OP_UNROT_FWD (forward role; replaces: rotate(x, -90k) + Shift2d((1,0)) + torch.cat of noise_network.py:213-222 applied
+     * to this layer's output).  When urot.p is set the launch is the layer over the four rotated copies of a batch (N = 4B images
+     * r*B + b, H == W = P, M = Mpad = 96): the output pixel (rB+b, y, x), y <= P-2, is stored at urot[b, i, j, r*M + m] -- the
+     * place SSDN_OP_UNROT_FWD would have moved it to -- and nothing goes to dst (which may be null); row y = P-1 is dropped and the
+     * rows of urot the one-row shift leaves empty are NOT written (they stay zero in a zero-initialised tensor).  urot_smask,
+     * optional: the LeakyReLU sign bytes of the output (ssdn_unrot_args.smask).  ssdn_conv_fuses_urot() tells whether a launch can. */
+    ssdn_view urot;
+    void* urot_smask;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -493,6 +501,8 @@ int ssdn_conv_fuses_pool(const ssdn_conv_args* a);
 int ssdn_conv_fuses_upsum(const ssdn_conv_args* a);
 /* 1 if SSDN_OP_CONV with these arguments applies the fused SSDN_OP_UNROT_BWD (ssdn_conv_args.unrot), 0 if it cannot. */
 int ssdn_conv_fuses_unrot(const ssdn_conv_args* a);
+/* 1 if SSDN_OP_CONV with these arguments stores its output un-rotated (fused SSDN_OP_UNROT_FWD, ssdn_conv_args.urot), 0 if it cannot. */
+int ssdn_conv_fuses_urot(const ssdn_conv_args* a);
 
 /* ssdn_run_ops executes a run of consecutive ops on one lane as ONE launch (k_conv_chain, csrc/conv_chain.hip: one workgroup per
  * image walks all layers with every tensor of the run resident in LDS) when the run is a "chain":

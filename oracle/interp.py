@@ -119,7 +119,7 @@ class Interp:
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
                 ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-                unrot=None, unrot_mask=None, unrot_smask=None):
+                unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -132,6 +132,9 @@ class Interp:
             out = torch.where(out > 0, out, LRELU * out)
         if dst32 is not None:
             self.t[dst32] = out.permute(0, 3, 1, 2).contiguous()
+            return
+        if urot is not None:       # fused SSDN_OP_UNROT_FWD of the (rounded) output; nothing goes to dst
+            self._unrot_fwd(_r16(out, self.fp16, self.plan.tensors[urot.t].kind), urot, N // 4, H, M, urot_smask)
             return
         if add is not None:
             out = out + self.view(add, M)
@@ -200,7 +203,9 @@ class Interp:
         return x.flip(1).transpose(1, 2)
 
     def op_unrot_fwd(self, src, dst, B, P, C, smask=None):
-        y = self.view(src, C)
+        self._unrot_fwd(self.view(src, C), dst, B, P, C, smask)
+
+    def _unrot_fwd(self, y, dst, B, P, C, smask=None):
         if smask is not None:     # bit q of byte k = (channel 8k+q > 0)
             pos = (y > 0).to(torch.int64).reshape(4 * B, P, P, C // 8, 8)
             self.t[smask] = (pos << torch.arange(8)).sum(-1).to(torch.uint8)

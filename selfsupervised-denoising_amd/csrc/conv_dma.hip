@@ -119,7 +119,8 @@ struct CdTile { int n, y0, x0; };
 
 // EPI: bit 0 = multiply by LeakyReLU'(mask), bit 1 = add the skip gradient (data-gradient role only), bit 2 = fused
 // SSDN_OP_UPSUM_BWD: a pass of the epilogue is 2 rows x 16 pixels = 8 low-resolution pixels, whose 2x2 sums times
-// LeakyReLU'(upsum_mask) are stored instead of the 32 pixels
+// LeakyReLU'(upsum_mask) are stored instead of the 32 pixels; bit 3 (forward role) = fused SSDN_OP_UNROT_FWD: every pixel goes to
+// its un-rotated place in ssdn_conv_args.urot (+ optional LeakyReLU sign bytes) instead of dst
 template <int MT, bool BF, int EPI>
 __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     constexpr int NWQ = MT * 3;               // 1 KiB DMA instructions per 48-channel weight slice; the 16-channel slice has MT
     constexpr int OSTR = MT * 64 + 16;        // epilogue: LDS bytes per pixel (16 B x odd: conflict-free ds_write_b128)
     constexpr int NEK = MT * 2;               // epilogue: 64-lane 16-byte row instructions per 32-pixel pass
-    constexpr bool HAS_MASK = (EPI & 1) != 0, HAS_ADD = (EPI & 2) != 0, HAS_UPS = (EPI & 4) != 0;
+    constexpr bool HAS_MASK = (EPI & 1) != 0, HAS_ADD = (EPI & 2) != 0, HAS_UPS = (EPI & 4) != 0, UROT = (EPI & 8) != 0;
     constexpr int NUK = (8 * MT * 4 + 63) / 64;   // upsum: 64-lane instructions per pass (8 pixels x cpp pieces)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -294,7 +295,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(UROT ? a.urot.p : a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_sgn = __builtin_amdgcn_make_buffer_rsrc(a.urot_smask, 0, (UROT && a.urot_smask) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const float slope = a.act ? LRELU_SLOPE : 1.f;
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, HAS_MASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(a.add.p, 0, HAS_ADD ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
@@ -409,12 +411,24 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         if (!CD_ABL(x, 8)) {
             char* reg = tbuf0 + (tpar ^ 1) * CD_TBYTES + w * (32 * OSTR);
             const int pix_t = (cur.n * a.H + cur.y0 + 4 * w) * a.W + cur.x0;     // first pixel of this wave's 4 rows
+            // fused UNROT_FWD: image n = r*B + b; the pixel (y, x) is S_r[u, v] with (u, v) = (y + 1, x) and lands at (b, i, j),
+            //   r=0: (i,j) = (u,v); r=1: (v, P-1-u); r=2: (P-1-u, P-1-v); r=3: (P-1-v, u)    -- as affine forms with uniform coefficients
+            int ur_base = 0, ur_iu = 0, ur_iv = 0, ur_ju = 0, ur_jv = 0;
+            if constexpr (UROT) {
+                const int Bq = a.N >> 2, P1 = a.H - 1;
+                const int r = (cur.n >= Bq ? 1 : 0) + (cur.n >= 2 * Bq ? 1 : 0) + (cur.n >= 3 * Bq ? 1 : 0);
+                ur_iu = r == 0 ? 1 : (r == 2 ? -1 : 0); ur_iv = r == 1 ? 1 : (r == 3 ? -1 : 0);
+                ur_ju = r == 3 ? 1 : (r == 1 ? -1 : 0); ur_jv = r == 0 ? 1 : (r == 2 ? -1 : 0);
+                const int i0 = r >= 2 ? P1 : 0, j0 = (r == 1 || r == 2) ? P1 : 0;
+                // element offset of destination pixel (b, i0, j0), channel block r
+                ur_base = (((cur.n - r * Bq) * a.H + i0) * a.W + j0) * a.urot.cs + a.urot.co + r * a.M;
+            }
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt) {
                 const int pix_p = pix_t + 2 * nt * a.W;
                 // operands of the data-gradient role: one batch of loads per pass, in flight while the accumulators are converted
                 u32x4_t ab[NEK], mb[NEK];
-                int goff[NEK];
+                int goff[NEK], soff[NEK];
 #pragma unroll
                 for (int k = 0; k < NEK; ++k) {
                     int epc = e_pc[k];
@@ -422,6 +436,13 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                     const bool on = epc >= 0;
                     const int px = epc & 255, c16 = (epc >> 8) << 4;
                     const int pix = pix_p + (px >> 4) * a.W + (px & 15);
+                    if constexpr (UROT) {
+                        const int u = cur.y0 + 4 * w + 2 * nt + (px >> 4) + 1, v = cur.x0 + (px & 15);
+                        const bool live = on && u < a.H;            // row P-1 falls off the shifted image
+                        const int dpx = (ur_iu * u + ur_iv * v) * a.W + ur_ju * u + ur_jv * v;
+                        goff[k] = live ? (ur_base + dpx * a.urot.cs + x.m_base) * 2 + c16 : (int)0x80000000;
+                        soff[k] = live ? pix * (a.M >> 3) + (x.m_base >> 3) + (c16 >> 4) : (int)0x80000000;
+                    } else
                     goff[k] = on ? (pix * a.dst.cs + a.dst.co + x.m_base) * 2 + c16 : (int)0x80000000;
                     if constexpr (HAS_ADD)
                         ab[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, on ? (pix * a.add.cs + a.add.co + x.m_base) * 2 + c16 : (int)0x80000000, 0, 0);
@@ -520,6 +541,15 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         }
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+                    if constexpr (UROT) {
+                        if (a.urot_smask) {      // sign byte of the piece: bit q = (channel q > 0), on the raw fp16 halves
+                            unsigned sb = 0;
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+                                sb |= ((int)(short)(o[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q) | (((int)o[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                            __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_sgn, soff[k], 0, 0);
+                        }
+                    }
                 }
                 }
             }
@@ -558,6 +588,8 @@ bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size) {
     if (a->c0 % 48 && a->c0 != a->Ktot) return false;           // a chunk never straddles the two sources
     if ((a->M & 7) || (a->Mpad & 31)) return false;
     if (!a->bf16 && (a->mask.p || a->add.p)) return false;      // mask / skip gradient: data-gradient role only
+    if (a->urot.p && (a->bf16 || a->M != 96 || a->Mpad != 96 || a->H != a->W || (a->N & 3) || a->mask.p || a->add.p || a->upsum.p || a->pool.p ||
+                      (a->urot.co & 7) || (a->urot.cs & 7) || (long long)(a->N / 4) * a->H * a->W * a->urot.cs * 2 >= (1ll << 31))) return false;
     if (a->upsum.p && (!a->bf16 || a->mask.p || a->add.p || a->upsum_c % 96 || a->upsum_c > a->M)) return false;
     // persistent grid: worth it from about one 256-pixel tile per CU upwards (smaller layers: k_conv's 32-channel blocks)
     int cus = ssdn_device_cus();
@@ -605,6 +637,10 @@ static int cd_launch(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
 
 template <int MT>
 static int cd_launch_role(const ssdn_conv_args* a, const CdAux& x, hipStream_t s) {
+    if (a->urot.p) {                               // fused UNROT_FWD: one 96-channel block (conv_dma_eligible)
+        if constexpr (MT == 3) return cd_launch<3, false, 8>(a, x, s);
+        return ssdn_set_error("conv_dma: fused UNROT_FWD needs M = 96");
+    }
     if (!a->bf16) return cd_launch<MT, false, 0>(a, x, s);
     if (a->upsum.p && x.m_base < a->upsum_c) {      // block of up-sampled-input channels: fused UPSUM_BWD (MT = 3 only)
         if constexpr (MT == 3) {

@@ -67,7 +67,8 @@ class DeviceNet:
         for name, spec in plan.tensors.items():
             if name in self.t:
                 continue
-            # zero-initialised once: padding channels / never-written slab corners must be finite
+            # zero-initialised once: padding channels / never-written slab corners must be finite, and the rows of `u` that the one-row
+            # shift of the un-rotation leaves empty are never written by the fused SSDN_OP_UNROT_FWD (ssdn_conv_args.urot): they ARE these zeros
             self.t[name] = torch.zeros(spec.shape, dtype=self.DT[spec.kind], device=device)
         self.fwd = OpList([self._mat(op) for op in plan.fwd])
         self._bwd_recs, self._bwd_layers = self._group_reductions(plan, [self._mat(op) for op in plan.bwd])
@@ -340,6 +341,10 @@ class DeviceNet:
                 raise L.SsdnHipError("conv %s: the plan fuses UPSUM_BWD but the library cannot (planner / library rule mismatch)" % a["layer"])
             s.unrot, s.unrot_mask = self._view(a.get("unrot")), self._view(a.get("unrot_mask"))
             s.unrot_smask = self.t[a["unrot_smask"]].data_ptr() if a.get("unrot_smask") else None
+            s.urot = self._view(a.get("urot"))
+            s.urot_smask = self.t[a["urot_smask"]].data_ptr() if a.get("urot_smask") else None
+            if a.get("urot") is not None and not L.load().ssdn_conv_fuses_urot(C.byref(s)):
+                raise L.SsdnHipError("conv %s: the plan fuses UNROT_FWD but the library cannot (planner / library rule mismatch)" % a["layer"])
             if a.get("unrot") is not None and not L.load().ssdn_conv_fuses_unrot(C.byref(s)):
                 raise L.SsdnHipError("conv %s: the plan fuses UNROT_BWD but the library cannot (planner / library rule mismatch)" % a["layer"])
             if L.load().ssdn_conv_lds_bytes(C.byref(s)) < 0:

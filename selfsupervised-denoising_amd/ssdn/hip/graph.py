@@ -29,6 +29,7 @@ WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient 
 #   "all": one launch behind the last data gradient; "buckets": one per gradient bucket (ssdn.hip.dp.bucket_layers);
 #   None: round 3's per-layer launches on the side lane
 WGRAD_MEGA = "split"
+FUSE_UNROT_FWD = True         # decode_block_1.2 stores its output un-rotated (no SSDN_OP_UNROT_FWD launch, no d1b tensor) where k_cdma serves it
 SIGN_BYTES = True             # the fused un-rotation of the backward pass reads LeakyReLU sign bytes (12 B/pixel) instead of d1b (192 B/pixel)
 MEGA_MIN_PX = 32768           # networks with fewer pixels (N*H*W) at full resolution keep the per-layer launches: a handful of tiles per
                               # layer is latency, not throughput (config 1's shape, batch 4 at 32x32: 0.66 ms per step vs 0.70 / 0.77)
@@ -323,7 +324,7 @@ class NetPlan:
 
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
               bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-              unrot=None, unrot_mask=None, unrot_smask=None):
+              unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None):
         """pool: view of the pooled tensor -- the conv's epilogue also writes Shift2d + MaxPool2d(2) of its output
         (ssdn_conv_args.pool).  Returns True if the pool was fused (the caller then emits no SSDN_OP_POOL_FWD)."""
         Ktot = c0 + c1
@@ -345,7 +346,8 @@ class NetPlan:
                                    pool=pool if (fused and pool is not None) else None,
                                    pool_shifted=int(pool_shifted) if (fused and pool is not None) else 0,
                                    upsum=upsum, upsum_mask=upsum_mask, upsum_c=int(upsum_c) if upsum is not None else 0,
-                                   unrot=unrot, unrot_mask=unrot_mask, unrot_smask=unrot_smask)))
+                                   unrot=unrot, unrot_mask=unrot_mask, unrot_smask=unrot_smask,
+                                   urot=urot, urot_smask=urot_smask)))
         return fused
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
@@ -500,9 +502,12 @@ class NetPlan:
         p5 = pool("p5", e5, H // 16, W // 16)
         e6 = enc("e6", "encode_block_6.0", p5, 48, H // 32, W // 32)
 
-        def dec(name_a, name_b, la, lb, up_src, c_up, skip, c_skip, h, w):
+        def dec(name_a, name_b, la, lb, up_src, c_up, skip, c_skip, h, w, urot=None, urot_smask=None):
             ta = self.act(name_a, N, h, w, 96)
             self._conv(f, L[la], "fwd", View(up_src), c_up, 1, View(skip), c_skip, N, h, w, t3, 96, dst=View(ta))
+            if urot is not None:      # the second conv stores un-rotated (fused SSDN_OP_UNROT_FWD): its own output tensor never exists
+                self._conv(f, L[lb], "fwd", View(ta), 96, 0, None, 0, N, h, w, t3, 96, dst=None, urot=View(urot), urot_smask=urot_smask)
+                return ta, None
             tb = self.act(name_b, N, h, w, 96)
             self._conv(f, L[lb], "fwd", View(ta), 96, 0, None, 0, N, h, w, t3, 96, dst=View(tb))
             return ta, tb
@@ -511,17 +516,24 @@ class NetPlan:
         d4a, d4b = dec("d4a", "d4b", "decode_block_4.0", "decode_block_4.2", d5b, 96, p3, 48, H // 8, W // 8)
         d3a, d3b = dec("d3a", "d3b", "decode_block_3.0", "decode_block_3.2", d4b, 96, p2, 48, H // 4, W // 4)
         d2a, d2b = dec("d2a", "d2b", "decode_block_2.0", "decode_block_2.2", d3b, 96, p1, 48, H // 2, W // 2)
-        d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W)
-
         nin = 384 if bs else 96
         if bs:
             u = self.act("u", B, H, W, 384)
             # with training: one LeakyReLU sign byte per 8 channels of d1b, for the fused un-rotation of the backward pass
             fused_unrot = H == W and H & (H - 1) == 0 and (B * H * W) % 256 == 0
             smk = self.T("smk_d1b", "u8", (N, H, W, 96 // 8)) if (self.train and SIGN_BYTES and fused_unrot) else None
-            f.append(Op("unrot_fwd", dict(src=View(d1b), dst=View(u), B=B, P=H, C=96, smask=smk)))
+            # decode_block_1.2 stores straight into `u` where the library's k_cdma serves it (csrc/conv_dma.hip::conv_dma_eligible:
+            # >= one 16x16 tile per CU; the engine cross-checks with ssdn_conv_fuses_urot).  d1b then never exists, so a training
+            # plan needs the sign bytes for its backward pass.
+            fused_urot = (FUSE_UNROT_FWD and H == W and H % 16 == 0 and N * (H // 16) * (W // 16) >= self.dev_cus and
+                          B * H * W * 384 * 2 < (1 << 31) and (smk is not None or not self.train))
+            d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W,
+                           urot=u if fused_urot else None, urot_smask=smk if fused_urot else None)
+            if not fused_urot:
+                f.append(Op("unrot_fwd", dict(src=View(d1b), dst=View(u), B=B, P=H, C=96, smask=smk)))
             head_in = u
         else:
+            d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W)
             head_in = d1b
         na = self.act("na", B, H, W, nin)
         self._conv(f, L["output_block.0"], "fwd", View(head_in), nin, 0, None, 0, B, H, W, TAPS_1x1, nin, dst=View(na))
@@ -586,8 +598,8 @@ class NetPlan:
         if bs and fused_unrot:
             # the data-gradient GEMM scatters its four 96-channel blocks straight into the rotated tensors (fused
             # SSDN_OP_UNROT_BWD, k_gdma; the library's rule: csrc/gemm_dma.hip::gemm_dma_eligible)
-            dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, None, unrot=View(g_d1b), unrot_mask=View(d1b),
-                  unrot_smask=smk)
+            dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, None, unrot=View(g_d1b),
+                  unrot_mask=View(d1b) if d1b is not None else None, unrot_smask=smk)
         elif bs:
             g_u = self.grad("g_u", B, H, W, 384)
             dgrad("output_block.0", g_na, 384, B, H, W, TAPS_1x1, 384, View(g_u))

@@ -104,6 +104,8 @@ def _out_of(op):
     if op.type == "conv":
         if a.get("unrot") is not None:          # fused UNROT_BWD: the launch's only output
             return ("act", a["unrot"], a["M"] // 4)
+        if a.get("urot") is not None:           # fused UNROT_FWD: the launch's only 16-bit output (+ sign bytes)
+            return ("act", a["urot"], 4 * a["M"])
         return ("f32", a["dst32"], None) if a["dst32"] is not None else ("act", a["dst"], a["M"])
     if op.type == "pool_fwd":
         return ("act", a["pooled"], a["C"])
@@ -126,7 +128,9 @@ def _out_of(op):
 # schedule of the hot shapes) run at test sizes too -- at cus = 256 they only trigger from BASELINE config 2 upwards
 # conv_mode (last field): 1 = the library's default kernel choice; 2 = the persistent LDS-DMA kernel k_cdma for every 3x3
 # layer of its shape class (>= 16x16 pixels), which by default only serves layers with >= 1 tile per CU (BASELINE sizes)
-CASES = [(3, 9, True, 2, 32, 0, 1), (1, 2, True, 1, 32, 0, 1), (3, 3, False, 2, 32, 0, 1), (3, 9, True, 1, 64, 0, 1), (3, 1, False, 2, 64, 0, 1),
+# (3, 9, True, 4, 64, 0, 1): 256 16x16 tiles at full resolution = one per CU of an MI355X, from where on decode_block_1.2 stores its output
+# un-rotated (fused SSDN_OP_UNROT_FWD in k_cdma) and the data gradients of the 64x64 stage fuse SSDN_OP_UPSUM_BWD
+CASES = [(3, 9, True, 2, 32, 0, 1), (1, 2, True, 1, 32, 0, 1), (3, 9, True, 4, 64, 0, 1), (3, 3, False, 2, 32, 0, 1), (3, 9, True, 1, 64, 0, 1), (3, 1, False, 2, 64, 0, 1),
          (3, 9, True, 8, 32, 0, 1), (3, 9, True, 2, 32, 8, 1), (3, 3, False, 2, 64, 6, 1),
          (3, 9, True, 2, 32, 0, 2), (1, 2, True, 1, 32, 0, 2), (3, 3, False, 2, 64, 0, 2), (3, 9, True, 3, 64, 0, 2), (3, 1, False, 5, 32, 0, 2)]
 
@@ -216,19 +220,35 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
         pv = op.a.get("pool") if op.type == "conv" else None
         if pv is not None:
             dn.t[pv.t][..., pv.co:pv.co + ch] = float("nan")
-        smk = op.a.get("smask") if op.type == "unrot_fwd" else None
+        smk = op.a.get("smask") if op.type == "unrot_fwd" else (op.a.get("urot_smask") if op.type == "conv" else None)
         if smk is not None:
             dn.t[smk].fill_(0xA5)
         OpList([rec]).run(current_stream())
         torch.cuda.synchronize()
+        if op.type == "conv" and op.a.get("urot") is not None:
+            # fused UNROT_FWD: the rows the one-row shift leaves empty are not the launch's to write (they stay as they were: zero
+            # in the zero-initialised tensor of a real run, NaN here); everything else is compared below
+            t, Cq, Pq = dn.t[dst.t], op.a["M"], op.a["H"]
+            empty = [t[:, 0, :, 0:Cq], t[:, :, Pq - 1, Cq:2 * Cq], t[:, Pq - 1, :, 2 * Cq:3 * Cq], t[:, :, 0, 3 * Cq:4 * Cq]]
+            if not all(bool(torch.isnan(e.float()).all()) for e in empty):
+                failures.append("op %d conv %s: fused UNROT_FWD wrote into the rows the shift leaves empty" % (i, op.a["layer"]))
+            for e in empty:
+                e.zero_()
         if smk is not None:
-            # LeakyReLU sign bytes of the un-rotated tensor: exact (the input is the forced one); row P-1 is not the kernel's to write
+            # LeakyReLU sign bytes of the un-rotated tensor; row P-1 is not the kernel's to write.  SSDN_OP_UNROT_FWD: exact (its input
+            # is the forced one).  Fused into the conv: exact against the signs of what the launch itself stored (un-rotated back)
             gots, wants = dn.t[smk].cpu(), it.t[smk]
+            if op.type == "conv":
+                Cq = op.a["M"]
+                own = dn.t[dst.t][..., dst.co:dst.co + 4 * Cq].float().cpu()
+                rows = torch.cat([it._rot(own[..., r * Cq:(r + 1) * Cq], ang)[:, 1:] for r, ang in enumerate((0, 90, 180, 270))], 0)
+                pos = (rows > 0).to(torch.int64).reshape(*rows.shape[:3], Cq // 8, 8)
+                wants = torch.cat([(pos << torch.arange(8)).sum(-1).to(torch.uint8), wants[:, -1:]], 1)
             if not torch.equal(gots[:, :-1], wants[:, :-1]):
-                failures.append("op %d unrot_fwd: %d sign bytes differ" % (i, int((gots[:, :-1] != wants[:, :-1]).sum())))
+                failures.append("op %d %s: %d sign bytes differ" % (i, op.type, int((gots[:, :-1] != wants[:, :-1]).sum())))
             if not bool((gots[:, -1] == 0xA5).all()):
-                failures.append("op %d unrot_fwd: sign bytes of the cut-off row were written" % i)
-            dn.t[smk].copy_(wants)
+                failures.append("op %d %s: sign bytes of the cut-off row were written" % (i, op.type))
+            dn.t[smk].copy_(it.t[smk])
         if pv is not None:
             # fused max-pool: exactly SSDN_OP_POOL_FWD of what the launch itself stored (max is exact on the rounded values)
             mine = dn.t[dst.t][..., dst.co:dst.co + ch].float().cpu()
@@ -513,6 +533,8 @@ def test_conv_chain_is_bit_identical(cin, cout, bs, B, P, min_chain, conv_chain_
         for name, t in dn.t.items():
             if t.dtype == torch.float16 and "/w" not in name:
                 t.fill_(float("nan"))
+        if any(op.type == "conv" and op.a.get("urot") is not None for op in plan.fwd):
+            dn.t["m/u"].zero_()       # (fused UNROT_FWD relies on the rows the shift leaves empty being zero from the allocation on)
         OpList(recs).run(current_stream())
         torch.cuda.synchronize()
         return {name: t.clone() for name, t in dn.t.items() if t.dtype in (torch.float16, torch.float32) and "/w" not in name}

@@ -17,20 +17,26 @@ def flat_params(plan, p):
     return flat
 
 
-@pytest.mark.parametrize("cin,cout,bs,B,P", [(3, 9, True, 2, 32), (1, 2, True, 1, 32), (3, 3, False, 2, 32), (3, 1, False, 1, 64)])
-def test_forward_backward_lowering(cin, cout, bs, B, P):
+# dev_cus = 8: the plan of a device with 8 CUs, on which the full-resolution layers of these small cases already have >= one tile per CU --
+# the fusions of the BASELINE sizes (decode_block_1.2 storing un-rotated + sign bytes, UPSUM_BWD in the data gradients) are lowered
+@pytest.mark.parametrize("cin,cout,bs,B,P,dev_cus", [(3, 9, True, 2, 32, None), (1, 2, True, 1, 32, None), (3, 3, False, 2, 32, None),
+                                                     (3, 1, False, 1, 64, None), (3, 9, True, 2, 32, 8), (1, 2, True, 1, 64, 8)])
+def test_forward_backward_lowering(cin, cout, bs, B, P, dev_cus):
     """float64 on both sides: in fp32 a handful of activations within 1e-7 of zero flip the LeakyReLU branch between two
     summation orders, which hides real bugs behind a 1e-3 noise floor; in fp64 the lowering must agree to ~1e-12."""
     torch.set_default_dtype(torch.float64)
     try:
-        _check_lowering(cin, cout, bs, B, P)
+        _check_lowering(cin, cout, bs, B, P, dev_cus)
     finally:
         torch.set_default_dtype(torch.float32)
 
 
-def _check_lowering(cin, cout, bs, B, P):
+def _check_lowering(cin, cout, bs, B, P, dev_cus=None):
     p = {k: v.double() for k, v in R.make_params(cin, cout, bs, seed=7).items()}
-    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=8)
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=8, dev_cus=dev_cus)
+    if dev_cus and bs:
+        assert not any(op.type == "unrot_fwd" for op in plan.fwd) and any(op.a.get("urot") is not None for op in plan.fwd if op.type == "conv")
+        assert "m/d1b" not in plan.tensors
     it = Interp(plan, flat_params(plan, p), fp16=False)
     x = R.hash_tensor((B, cin, P, P), 91, 0, 1).double()
     it.t["m/in32"] = x.clone()
