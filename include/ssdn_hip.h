@@ -35,7 +35,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SSDN_ABI_VERSION 11
+#define SSDN_ABI_VERSION 12
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -174,6 +174,12 @@ typedef struct ssdn_conv_args {
      * optional: the LeakyReLU sign bytes of the output (ssdn_unrot_args.smask).  ssdn_conv_fuses_urot() tells whether a launch can. */
     ssdn_view urot;
     void* urot_smask;
+    /* LeakyReLU sign bytes instead of saved activations in the backward pass (both optional; ssdn_conv_signs() tells whether a launch
+     * honours them): sign_out (forward role, 16-bit dst) -- the launch also writes one byte per 8 output channels, bit q of byte
+     * [pixel][k] = (output channel 8k+q > 0), [N*H*W][M/8]; mask_sign (data-gradient role) -- such bytes for the tensor `mask` views,
+     * read instead of it (same result: only the sign of the activation enters LeakyReLU'; 1/16 of the bytes). */
+    void* sign_out;
+    const void* mask_sign;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -503,6 +509,8 @@ int ssdn_conv_fuses_upsum(const ssdn_conv_args* a);
 int ssdn_conv_fuses_unrot(const ssdn_conv_args* a);
 /* 1 if SSDN_OP_CONV with these arguments stores its output un-rotated (fused SSDN_OP_UNROT_FWD, ssdn_conv_args.urot), 0 if it cannot. */
 int ssdn_conv_fuses_urot(const ssdn_conv_args* a);
+/* 1 if SSDN_OP_CONV with these arguments writes sign_out / reads mask_sign (whichever are set), 0 if it cannot. */
+int ssdn_conv_signs(const ssdn_conv_args* a);
 
 /* ssdn_run_ops executes a run of consecutive ops on one lane as ONE launch (k_conv_chain, csrc/conv_chain.hip: one workgroup per
  * image walks all layers with every tensor of the run resident in LDS) when the run is a "chain":

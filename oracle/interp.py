@@ -30,6 +30,17 @@ def _lgrad(act):
     return torch.where(act > 0, torch.ones_like(act), torch.full_like(act, LRELU))
 
 
+def _pack_signs(y):
+    """LeakyReLU sign bytes (include/ssdn_hip.h, sign_out / smask): bit q of byte k = (channel 8k+q > 0)"""
+    pos = (y > 0).to(torch.int64).reshape(*y.shape[:-1], y.shape[-1] // 8, 8)
+    return (pos << torch.arange(8)).sum(-1).to(torch.uint8)
+
+
+def _unpack_signs(b, C):
+    bits = (b.to(torch.int64)[..., None] >> torch.arange(8)) & 1
+    return bits.reshape(*b.shape[:-1], -1)[..., :C]
+
+
 class Interp:
     def __init__(self, plan, flat_params: torch.Tensor, fp16: bool = False):
         self.plan, self.fp16 = plan, fp16
@@ -119,7 +130,7 @@ class Interp:
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
                 ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-                unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None):
+                unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None, sign_out=None, mask_sign=None):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -138,7 +149,9 @@ class Interp:
             return
         if add is not None:
             out = out + self.view(add, M)
-        if mask is not None:
+        if mask_sign is not None:      # sign bytes of the tensor `mask` views (written by its producer: sign_out)
+            out = out * torch.where(_unpack_signs(self.t[mask_sign], M) > 0, 1.0, LRELU)
+        elif mask is not None:
             out = out * _lgrad(self.view(mask, M))
         if unrot is not None:      # fused SSDN_OP_UNROT_BWD of the (rounded) output; nothing goes to dst
             C4 = M // 4
@@ -148,8 +161,7 @@ class Interp:
                 gs = self._rot(g[..., r * C4:(r + 1) * C4], ang)
                 outs.append(torch.cat([gs[:, 1:], torch.zeros(N, 1, W, C4)], 1))
             if unrot_smask is not None:      # the sign bytes SSDN_OP_UNROT_FWD left (rows y <= P-2; row P-1 only meets zeros)
-                bits = (self.t[unrot_smask].to(torch.int64)[..., None] >> torch.arange(8)) & 1
-                lg = torch.where(bits.reshape(*bits.shape[:3], -1)[..., :C4] > 0, 1.0, LRELU)
+                lg = torch.where(_unpack_signs(self.t[unrot_smask], C4) > 0, 1.0, LRELU)
             else:
                 lg = _lgrad(self.view(unrot_mask, C4))
             self.store(unrot, C4, torch.cat(outs, 0) * lg)
@@ -162,6 +174,8 @@ class Interp:
                 self.alloc(dst.t)[..., dst.co + upsum_c:dst.co + M] = _r16(out[..., upsum_c:], self.fp16, self.plan.tensors[dst.t].kind)
             return
         self.store(dst, M, out)
+        if sign_out is not None:
+            self.t[sign_out] = _pack_signs(self.view(dst, M))
         if pool is not None:       # fused SSDN_OP_POOL_FWD of the stored (rounded) output
             self.store(pool, M, self._windows(self.view(dst, M), pool_shifted).max(3).values)
 
@@ -207,8 +221,7 @@ class Interp:
 
     def _unrot_fwd(self, y, dst, B, P, C, smask=None):
         if smask is not None:     # bit q of byte k = (channel 8k+q > 0)
-            pos = (y > 0).to(torch.int64).reshape(4 * B, P, P, C // 8, 8)
-            self.t[smask] = (pos << torch.arange(8)).sum(-1).to(torch.uint8)
+            self.t[smask] = _pack_signs(y)
         s = torch.cat([torch.zeros(4 * B, 1, P, C), y[:, :-1]], 1)
         parts = [self._rot(s[r * B:(r + 1) * B], a) for r, a in enumerate((0, 270, 180, 90))]
         self.store(dst, 4 * C, torch.cat(parts, -1))

@@ -145,6 +145,7 @@ int ssdn_conv_fuses_pool(const ssdn_conv_args* a) { return a && conv_fuses_pool(
 int ssdn_conv_fuses_upsum(const ssdn_conv_args* a) { return a && conv_fuses_upsum(a) ? 1 : 0; }
 int ssdn_conv_fuses_unrot(const ssdn_conv_args* a) { return a && conv_fuses_unrot(a) ? 1 : 0; }
 int ssdn_conv_fuses_urot(const ssdn_conv_args* a) { return a && conv_fuses_urot(a) ? 1 : 0; }
+int ssdn_conv_signs(const ssdn_conv_args* a) { return a && conv_signs(a) ? 1 : 0; }
 
 #define SSDN_NEVENTS 256
 #define SSDN_NLANES 4

@@ -59,7 +59,8 @@ __device__ __forceinline__ void gd_wait_groups(int n) {
 
 // wave grid NWP (pixels) x NWM (channels); a wave owns WP x 32 pixels and WM x 32 output channels.  EPI bit 0: LeakyReLU' mask;
 // bit 2: the next narrow 1x1 layer computed from the output tile (GdAux.w4);
-// bit 1: fused SSDN_OP_UNROT_BWD (the 96-channel block r of a pixel goes, times LeakyReLU', to its place in rotation r's tensor).
+// bit 1: fused SSDN_OP_UNROT_BWD (the 96-channel block r of a pixel goes, times LeakyReLU', to its place in rotation r's tensor);
+// bit 3: the LeakyReLU' operand of bit 0 / bit 1 arrives as sign bytes (mask_sign / unrot_smask); bit 4: sign bytes of the output (sign_out).
 // PERSISTENT: a workgroup walks tiles blockIdx.x, blockIdx.x + gridDim.x, ...; the two operand rings run on as one chunk stream
 // across tile boundaries, so the loads of tile i+1 are in flight while tile i is converted and stored (the epilogue has its own
 // LDS region: wave-private transposes of EG channel tiles at a time).
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     constexpr int EG = gd_eg(WM), NEG = WM / EG;             // epilogue: channel tiles per transpose group
     constexpr int OSTR = EG * 64 + 16, NEK = EG * 2, CPP = EG * 4;
     constexpr int BOFF = DA * ABYTES, EOFF = BOFF + DB * BBYTES, BIAS_OFF = EOFF + NW * 32 * OSTR, DUMMY_OFF = BIAS_OFF + TM * 4;
-    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0, OUT4 = (EPI & 4) != 0, SMASK = (EPI & 8) != 0;
+    constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0, OUT4 = (EPI & 4) != 0, SMASK = (EPI & 8) != 0, SOUT = (EPI & 16) != 0;
     static_assert(!OUT4 || (NWM == 1 && WM == 3 && gd_eg(WM) == 3 && !BF), "the fused narrow layer needs the wave's whole 96-channel tile in its LDS region");
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -92,7 +93,8 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_um = __builtin_amdgcn_make_buffer_rsrc(a.unrot_mask.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_us = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.unrot_smask), 0, SMASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_us = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(UNROT ? a.unrot_smask : a.mask_sign), 0, SMASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_so = __builtin_amdgcn_make_buffer_rsrc(a.sign_out, 0, SOUT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
 
     // DMA lane constants: lane -> (row lane >> 2 of a 16-row instruction, LDS piece lane & 3); the piece fetched is the swizzled one
     const int drow = lane >> 2, dpiece = (lane & 3) ^ ((drow >> 2) & 3);
@@ -275,7 +277,8 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                             mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
                     } else {
                         goff[k] = (pix * a.dst.cs + a.dst.co + chb) * 2 + c16;
-                        if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + chb) * 2 + c16, 0, 0);
+                        if constexpr (HAS_MASK && SMASK) mb[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_us, pix * (a.M >> 3) + (chb >> 3) + (c16 >> 4), 0, 0);
+                        else if constexpr (HAS_MASK) mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, (pix * a.mask.cs + a.mask.co + chb) * 2 + c16, 0, 0);
                     }
                 }
 #pragma unroll
@@ -300,6 +303,14 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                     }
                     if constexpr (UNROT) __builtin_amdgcn_raw_buffer_store_b128(o, rs_ur, goff[k], 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
+                    if constexpr (SOUT) {      // sign byte of the piece: bit q = (channel q > 0), on the raw fp16 halves
+                        unsigned sb = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            sb |= ((int)(short)(o[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q) | (((int)o[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                        const int p = k * 64 + lane, px = p / CPP, c16 = (p - px * CPP) << 4;
+                        __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_so, (pix_p + px) * (a.M >> 3) + (chb >> 3) + (c16 >> 4), 0, 0);
+                    }
                 }
             }
         }
@@ -321,6 +332,15 @@ bool gemm_dma_eligible(const ssdn_conv_args* a) {
     csmax = csmax > a->mask.cs ? csmax : a->mask.cs;
     if (px * csmax * 2 >= (1ll << 31)) return false;
     if ((a->src0.co & 7) || (a->src0.cs & 7)) return false;
+    return true;
+}
+
+// sign_out: the forward role of a 384-channel layer (16-bit output, no fused narrow layer behind it); mask_sign: its data-gradient
+// role with a mask (not the fused un-rotation, which has unrot_smask)
+bool gemm_dma_signs(const ssdn_conv_args* a) {
+    if (!gemm_dma_eligible(a) || a->Mpad != 384 || a->unrot.p) return false;
+    if (a->sign_out && (a->bf16 || !a->dst.p)) return false;
+    if (a->mask_sign && (!a->bf16 || !a->mask.p)) return false;
     return true;
 }
 
@@ -364,8 +384,9 @@ int launch_gemm_dma(const ssdn_conv_args* a, hipStream_t s) {
     const int epi = a->mask.p ? 1 : 0;
     if (a->unrot.p) return a->unrot_smask ? gd_launch<2, 6, 4, 2, true, 10>(a, s) : gd_launch<2, 6, 4, 2, true, 2>(a, s);
     if (a->Mpad == 384) {
-        if (!a->bf16) return gd_launch<2, 6, 4, 2, false, 0>(a, s);
-        return epi ? gd_launch<2, 6, 4, 2, true, 1>(a, s) : gd_launch<2, 6, 4, 2, true, 0>(a, s);
+        if (!a->bf16) return a->sign_out ? gd_launch<2, 6, 4, 2, false, 16>(a, s) : gd_launch<2, 6, 4, 2, false, 0>(a, s);
+        if (epi) return a->mask_sign ? gd_launch<2, 6, 4, 2, true, 9>(a, s) : gd_launch<2, 6, 4, 2, true, 1>(a, s);
+        return gd_launch<2, 6, 4, 2, true, 0>(a, s);
     }
     if (!a->bf16) return gd_launch<1, 3, 8, 1, false, 0>(a, s);
     return epi ? gd_launch<1, 3, 8, 1, true, 1>(a, s) : gd_launch<1, 3, 8, 1, true, 0>(a, s);

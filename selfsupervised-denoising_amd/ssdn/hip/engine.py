@@ -341,6 +341,10 @@ class DeviceNet:
                 raise L.SsdnHipError("conv %s: the plan fuses UPSUM_BWD but the library cannot (planner / library rule mismatch)" % a["layer"])
             s.unrot, s.unrot_mask = self._view(a.get("unrot")), self._view(a.get("unrot_mask"))
             s.unrot_smask = self.t[a["unrot_smask"]].data_ptr() if a.get("unrot_smask") else None
+            s.sign_out = self.t[a["sign_out"]].data_ptr() if a.get("sign_out") else None
+            s.mask_sign = self.t[a["mask_sign"]].data_ptr() if a.get("mask_sign") else None
+            if (a.get("sign_out") or a.get("mask_sign")) and not L.load().ssdn_conv_signs(C.byref(s)):
+                raise L.SsdnHipError("conv %s: the plan uses sign bytes but the library cannot (planner / library rule mismatch)" % a["layer"])
             s.urot = self._view(a.get("urot"))
             s.urot_smask = self.t[a["urot_smask"]].data_ptr() if a.get("urot_smask") else None
             if a.get("urot") is not None and not L.load().ssdn_conv_fuses_urot(C.byref(s)):

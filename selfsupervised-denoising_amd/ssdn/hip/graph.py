@@ -30,6 +30,7 @@ WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient 
 #   None: round 3's per-layer launches on the side lane
 WGRAD_MEGA = "split"
 FUSE_UNROT_FWD = True         # decode_block_1.2 stores its output un-rotated (no SSDN_OP_UNROT_FWD launch, no d1b tensor) where k_cdma serves it
+SIGN_BYTES_HEAD = True        # output_block.0 leaves sign bytes of its 384-channel output for the data gradient of output_block.2
 SIGN_BYTES = True             # the fused un-rotation of the backward pass reads LeakyReLU sign bytes (12 B/pixel) instead of d1b (192 B/pixel)
 MEGA_MIN_PX = 32768           # networks with fewer pixels (N*H*W) at full resolution keep the per-layer launches: a handful of tiles per
                               # layer is latency, not throughput (config 1's shape, batch 4 at 32x32: 0.66 ms per step vs 0.70 / 0.77)
@@ -324,7 +325,7 @@ class NetPlan:
 
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
               bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-              unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None):
+              unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None, sign_out=None, mask_sign=None):
         """pool: view of the pooled tensor -- the conv's epilogue also writes Shift2d + MaxPool2d(2) of its output
         (ssdn_conv_args.pool).  Returns True if the pool was fused (the caller then emits no SSDN_OP_POOL_FWD)."""
         Ktot = c0 + c1
@@ -347,7 +348,7 @@ class NetPlan:
                                    pool_shifted=int(pool_shifted) if (fused and pool is not None) else 0,
                                    upsum=upsum, upsum_mask=upsum_mask, upsum_c=int(upsum_c) if upsum is not None else 0,
                                    unrot=unrot, unrot_mask=unrot_mask, unrot_smask=unrot_smask,
-                                   urot=urot, urot_smask=urot_smask)))
+                                   urot=urot, urot_smask=urot_smask, sign_out=sign_out, mask_sign=mask_sign)))
         return fused
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
@@ -536,7 +537,10 @@ class NetPlan:
             d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W)
             head_in = d1b
         na = self.act("na", B, H, W, nin)
-        self._conv(f, L["output_block.0"], "fwd", View(head_in), nin, 0, None, 0, B, H, W, TAPS_1x1, nin, dst=View(na))
+        # the 384-channel head layer of a training plan leaves LeakyReLU sign bytes for the data gradient of output_block.2 (k_gdma serves
+        # both: csrc/gemm_dma.hip::gemm_dma_signs; the engine cross-checks with ssdn_conv_signs)
+        smk_na = self.T("smk_na", "u8", (B, H, W, nin // 8)) if (self.train and SIGN_BYTES_HEAD and nin == 384 and (B * H * W) % 256 == 0) else None
+        self._conv(f, L["output_block.0"], "fwd", View(head_in), nin, 0, None, 0, B, H, W, TAPS_1x1, nin, dst=View(na), sign_out=smk_na)
         nb = self.act("nb", B, H, W, 96)
         self._conv(f, L["output_block.2"], "fwd", View(na), nin, 0, None, 0, B, H, W, TAPS_1x1, 96, dst=View(nb))
         out32 = self.T("out32", "f32", (B, self.Cout, H, W))
@@ -590,7 +594,7 @@ class NetPlan:
         blocks = list(range(0, nin, 96))
         self._wgrad(lo2, View(g_nb), 96, View(na), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, cblocks=blocks)
         g_na = self.grad("g_na", B, H, W, nin)
-        dgrad("output_block.2", g_nb, 96, B, H, W, TAPS_1x1, nin, View(g_na), mask=View(na))
+        dgrad("output_block.2", g_nb, 96, B, H, W, TAPS_1x1, nin, View(g_na), mask=View(na), mask_sign=smk_na)
         # output_block.0 : nin -> nin
         lo0 = L["output_block.0"]
         self._wgrad(lo0, View(g_na), 96, View(head_in), nin, 0, None, 0, nin, B, H, W, TAPS_1x1, cblocks=blocks, mblocks=nin // 96)

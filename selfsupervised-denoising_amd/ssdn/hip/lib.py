@@ -39,7 +39,7 @@ class ConvArgs(C.Structure):
                 ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32), ("bf16", i32), ("wc", vp), ("kreal", i32),
                 ("pool", View), ("pool_shifted", i32), ("upsum", View), ("upsum_mask", View), ("upsum_c", i32),
                 ("unrot", View), ("unrot_mask", View), ("unrot_smask", vp),
-                ("urot", View), ("urot_smask", vp)]
+                ("urot", View), ("urot_smask", vp), ("sign_out", vp), ("mask_sign", vp)]
 
 
 class PoolArgs(C.Structure):
@@ -128,12 +128,12 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
                  mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, metrics=MetricsArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 11      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 12      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
-           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_conv_fuses_urot", "ssdn_chain_len",
+           "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_conv_fuses_urot", "ssdn_conv_signs", "ssdn_chain_len",
            "ssdn_conv_set_chain", "ssdn_wgrad_mega_ok", "ssdn_wgrad_variant"]
 PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6, wgrad_side=7)
 
@@ -182,6 +182,8 @@ def load() -> C.CDLL:
     lib.ssdn_conv_fuses_unrot.restype = C.c_int
     lib.ssdn_conv_fuses_urot.argtypes = [C.c_void_p]
     lib.ssdn_conv_fuses_urot.restype = C.c_int
+    lib.ssdn_conv_signs.argtypes = [C.c_void_p]
+    lib.ssdn_conv_signs.restype = C.c_int
     lib.ssdn_conv_fuses_upsum.argtypes = [C.c_void_p]
     lib.ssdn_conv_fuses_upsum.restype = C.c_int
     lib.ssdn_conv_fuses_pool.argtypes = [C.c_void_p]

@@ -220,7 +220,7 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
         pv = op.a.get("pool") if op.type == "conv" else None
         if pv is not None:
             dn.t[pv.t][..., pv.co:pv.co + ch] = float("nan")
-        smk = op.a.get("smask") if op.type == "unrot_fwd" else (op.a.get("urot_smask") if op.type == "conv" else None)
+        smk = op.a.get("smask") if op.type == "unrot_fwd" else ((op.a.get("urot_smask") or op.a.get("sign_out")) if op.type == "conv" else None)
         if smk is not None:
             dn.t[smk].fill_(0xA5)
         OpList([rec]).run(current_stream())
@@ -238,7 +238,14 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
             # LeakyReLU sign bytes of the un-rotated tensor; row P-1 is not the kernel's to write.  SSDN_OP_UNROT_FWD: exact (its input
             # is the forced one).  Fused into the conv: exact against the signs of what the launch itself stored (un-rotated back)
             gots, wants = dn.t[smk].cpu(), it.t[smk]
-            if op.type == "conv":
+            if op.type == "conv" and op.a.get("sign_out"):
+                # sign_out: exactly the signs of the output the launch itself stored, every pixel
+                from interp import _pack_signs
+                own = _pack_signs(dn.t[dst.t][..., dst.co:dst.co + ch].float().cpu())
+                if not torch.equal(gots, own):
+                    failures.append("op %d conv %s: %d sign bytes differ from the signs of the stored output" % (i, op.a["layer"], int((gots != own).sum())))
+                gots = wants = torch.full_like(gots, 0xA5)      # (nothing more to check below)
+            elif op.type == "conv":
                 Cq = op.a["M"]
                 own = dn.t[dst.t][..., dst.co:dst.co + 4 * Cq].float().cpu()
                 rows = torch.cat([it._rot(own[..., r * Cq:(r + 1) * Cq], ang)[:, 1:] for r, ang in enumerate((0, 90, 180, 270))], 0)
