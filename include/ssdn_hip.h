@@ -35,7 +35,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SSDN_ABI_VERSION 12
+#define SSDN_ABI_VERSION 13
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -177,9 +177,11 @@ typedef struct ssdn_conv_args {
     /* LeakyReLU sign bytes instead of saved activations in the backward pass (both optional; ssdn_conv_signs() tells whether a launch
      * honours them): sign_out (forward role, 16-bit dst) -- the launch also writes one byte per 8 output channels, bit q of byte
      * [pixel][k] = (output channel 8k+q > 0), [N*H*W][M/8]; mask_sign (data-gradient role) -- such bytes for the tensor `mask` views,
-     * read instead of it (same result: only the sign of the activation enters LeakyReLU'; 1/16 of the bytes). */
+     * read instead of it (same result: only the sign of the activation enters LeakyReLU'; 1/16 of the bytes); upsum_mask_sign
+     * (data-gradient role with the fused SSDN_OP_UPSUM_BWD) -- such bytes for the tensor `upsum_mask` views, [N*(H/2)*(W/2)][upsum_c/8]. */
     void* sign_out;
     const void* mask_sign;
+    const void* upsum_mask_sign;
 } ssdn_conv_args;
 
 /* ---- SSDN_OP_POOL_FWD / SSDN_OP_POOL_BWD ----------------------------------------------------
@@ -187,7 +189,10 @@ typedef struct ssdn_conv_args {
  * backward fused with the LeakyReLU backward of the producing conv.
  * shifted: window rows {2i-1, 2i}, row -1 is a literal 0 that takes part in the max; else rows {2i, 2i+1}.
  * BWD: dz(n,y,x,c) = (first position in window scan order whose value equals the pooled max is (y,x))
- *                    ? dpool(n,i,j,c) * (act > 0 ? 1 : 0.1) : 0;  if the zero pad row wins the gradient is dropped. */
+ *                    ? dpool(n,i,j,c) * (act > 0 ? 1 : 0.1) : 0;  if the zero pad row wins the gradient is dropped.
+ * route (optional, uint32 [N,H/2,W/2,C/8]): FWD also writes one word per (window, 8 channels) -- nibble q of channel 8k+q: bits 0-1 = scan
+ *   position of the first maximum, bit 2 = the zero pad row holds it, bit 3 = the maximum is > 0; BWD launched on its own reads the word
+ *   instead of the four activation pieces of the window (same result, 4 bytes instead of 64; a chained launch keeps reading `act`). */
 typedef struct ssdn_pool_args {
     ssdn_view act;    /* [N,H,W,C] full-res post-activation */
     ssdn_view pooled; /* [N,H/2,W/2,C]  (FWD: output, BWD: input) */
@@ -195,6 +200,7 @@ typedef struct ssdn_pool_args {
     ssdn_view dz;     /* BWD only: [N,H,W,C] */
     int32_t N, H, W, C;
     int32_t shifted;
+    void* route;
 } ssdn_pool_args;
 
 /* ---- SSDN_OP_UPSUM_BWD ----------------------------------------------------------------------

@@ -130,7 +130,7 @@ class Interp:
 
     def op_conv(self, layer, role, src0, src1, c0, c1, up0, N, H, W, taps, M, Mpad, Ktot, bias, act, mask, add, dst, dst32,
                 ltw, lth, ltn, kc, bf16=0, kreal=0, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-                unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None, sign_out=None, mask_sign=None):
+                unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None, sign_out=None, mask_sign=None, upsum_mask_sign=None):
         x = self._gather(src0, src1, c0, c1, up0, N, H, W)
         wp = self.t[self.plan.prefix + ("wf/" if role == "fwd" else "wd/") + layer]
         assert wp.shape == (len(taps), Mpad, Ktot), (wp.shape, len(taps), Mpad, Ktot)
@@ -169,7 +169,11 @@ class Interp:
         if upsum is not None:      # fused SSDN_OP_UPSUM_BWD of the (rounded) channels below upsum_c; the rest goes to dst
             r = _r16(out[..., :upsum_c], self.fp16, self.plan.tensors[dst.t].kind)
             sm = r.reshape(N, H // 2, 2, W // 2, 2, upsum_c).sum((2, 4))
-            self.store(upsum, upsum_c, sm * _lgrad(self.view(upsum_mask, upsum_c)))
+            if upsum_mask_sign is not None:      # sign bytes of the tensor `upsum_mask` views (written by its producer: sign_out)
+                lg = torch.where(_unpack_signs(self.t[upsum_mask_sign], upsum_c) > 0, 1.0, LRELU)
+            else:
+                lg = _lgrad(self.view(upsum_mask, upsum_c))
+            self.store(upsum, upsum_c, sm * lg)
             if M > upsum_c:
                 self.alloc(dst.t)[..., dst.co + upsum_c:dst.co + M] = _r16(out[..., upsum_c:], self.fp16, self.plan.tensors[dst.t].kind)
             return
@@ -186,11 +190,24 @@ class Interp:
             a = torch.cat([torch.zeros(N, 1, W, C), a[:, :-1]], 1)
         return a.reshape(N, H // 2, 2, W // 2, 2, C).permute(0, 1, 3, 2, 4, 5).reshape(N, H // 2, W // 2, 4, C)
 
-    def op_pool_fwd(self, act, pooled, N, H, W, C, shifted):
+    def op_pool_fwd(self, act, pooled, N, H, W, C, shifted, route=None):
         w = self._windows(self.view(act, C), shifted)
         self.store(pooled, C, w.max(3).values)
+        if route is not None:      # include/ssdn_hip.h, ssdn_pool_args.route: nibble = first maximum's scan position | pad row wins << 2 | max > 0 << 3
+            mx = w.max(3).values
+            hit = (w == mx.unsqueeze(3))
+            pos = (hit & (hit.cumsum(3) == 1)).to(torch.int64).argmax(3)            # [N,Ho,Wo,C]
+            nib = pos
+            if shifted:            # the literal zero row is scanned first: on the top row of windows it holds every maximum <= 0
+                top = torch.zeros_like(mx, dtype=torch.bool)
+                top[:, 0] = True
+                nib = torch.where(top & (mx <= 0), torch.full_like(pos, 4), pos)
+            nib = nib | ((mx > 0).to(torch.int64) << 3)
+            sh = (4 * torch.arange(8, dtype=torch.int64)).repeat(C // 8)
+            words = (nib << sh).reshape(N, H // 2, W // 2, C // 8, 8).sum(-1)
+            self.t[route] = words.to(torch.int64)
 
-    def op_pool_bwd(self, act, dpool, dz, N, H, W, C, shifted):
+    def op_pool_bwd(self, act, dpool, dz, N, H, W, C, shifted, route=None):
         a = self.view(act, C)
         w = self._windows(a, shifted)
         mx = w.max(3, keepdim=True).values

@@ -153,6 +153,7 @@ bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size);
 int conv_dma_lds_bytes(int mt);
 bool conv_signs(const ssdn_conv_args* a);                      // conv_mfma.hip: the launch honours sign_out / mask_sign (k_gdma, M = 384)
 bool gemm_dma_signs(const ssdn_conv_args* a);
+bool conv_dma_signs(const ssdn_conv_args* a);                  // conv_dma.hip: k_cdma writes / reads LeakyReLU sign bytes for this launch
 bool conv_fuses_urot(const ssdn_conv_args* a);                 // conv_mfma.hip: k_cdma stores un-rotated (fused UNROT_FWD)
 bool conv_fuses_unrot(const ssdn_conv_args* a);                // conv_mfma.hip: k_gdma applies the fused UNROT_BWD
 bool conv_fuses_upsum(const ssdn_conv_args* a);                // conv_mfma.hip: k_cdma or the flat path applies the fused UPSUM_BWD

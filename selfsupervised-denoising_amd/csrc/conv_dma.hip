@@ -120,7 +120,9 @@ struct CdTile { int n, y0, x0; };
 // EPI: bit 0 = multiply by LeakyReLU'(mask), bit 1 = add the skip gradient (data-gradient role only), bit 2 = fused
 // SSDN_OP_UPSUM_BWD: a pass of the epilogue is 2 rows x 16 pixels = 8 low-resolution pixels, whose 2x2 sums times
 // LeakyReLU'(upsum_mask) are stored instead of the 32 pixels; bit 3 (forward role) = fused SSDN_OP_UNROT_FWD: every pixel goes to
-// its un-rotated place in ssdn_conv_args.urot (+ optional LeakyReLU sign bytes) instead of dst
+// its un-rotated place in ssdn_conv_args.urot (+ optional LeakyReLU sign bytes) instead of dst; bit 4 (forward role) = the launch also
+// writes the LeakyReLU sign bytes of its output (ssdn_conv_args.sign_out); bit 5 (data-gradient role, with bit 0 or bit 2) = the
+// LeakyReLU' operand arrives as sign bytes (mask_sign / upsum_mask_sign: one byte per 16-byte piece instead of the piece)
 template <int MT, bool BF, int EPI>
 __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -130,6 +132,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     constexpr int OSTR = MT * 64 + 16;        // epilogue: LDS bytes per pixel (16 B x odd: conflict-free ds_write_b128)
     constexpr int NEK = MT * 2;               // epilogue: 64-lane 16-byte row instructions per 32-pixel pass
     constexpr bool HAS_MASK = (EPI & 1) != 0, HAS_ADD = (EPI & 2) != 0, HAS_UPS = (EPI & 4) != 0, UROT = (EPI & 8) != 0;
+    constexpr bool SOUT = (EPI & 16) != 0, SMASK = (EPI & 32) != 0;
     constexpr int NUK = (8 * MT * 4 + 63) / 64;   // upsum: 64-lane instructions per pass (8 pixels x cpp pieces)
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -296,7 +299,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     __builtin_amdgcn_s_barrier();
 
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(UROT ? a.urot.p : a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_sgn = __builtin_amdgcn_make_buffer_rsrc(a.urot_smask, 0, (UROT && a.urot_smask) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_sgn = __builtin_amdgcn_make_buffer_rsrc(SOUT ? a.sign_out : a.urot_smask, 0, (SOUT || (UROT && a.urot_smask)) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_ms = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_UPS ? a.upsum_mask_sign : a.mask_sign), 0, SMASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const float slope = a.act ? LRELU_SLOPE : 1.f;
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, HAS_MASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(a.add.p, 0, HAS_ADD ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
@@ -446,8 +450,11 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                     goff[k] = on ? (pix * a.dst.cs + a.dst.co + x.m_base) * 2 + c16 : (int)0x80000000;
                     if constexpr (HAS_ADD)
                         ab[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, on ? (pix * a.add.cs + a.add.co + x.m_base) * 2 + c16 : (int)0x80000000, 0, 0);
-                    if constexpr (HAS_MASK)
+                    if constexpr (HAS_MASK && SMASK)      // one sign byte per 16-byte piece (written by the producer: sign_out), M / 8 bytes per pixel
+                        mb[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_ms, on ? pix * (a.M >> 3) + (x.m_base >> 3) + (c16 >> 4) : (int)0x80000000, 0, 0);
+                    else if constexpr (HAS_MASK)
                         mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, on ? (pix * a.mask.cs + a.mask.co + x.m_base) * 2 + c16 : (int)0x80000000, 0, 0);
+                    if constexpr (SOUT) soff[k] = on ? pix * (a.M >> 3) + (x.m_base >> 3) + (c16 >> 4) : (int)0x80000000;
                 }
                 // registers -> LDS: lane (pixel l31, kh) holds channels 32 mt + 8 g + 4 kh + (0..3) in acc[mt][nt][4g..4g+3];
                 // v_permlane32_swap pairs group g of the kh = 1 lanes with group g+1 of the kh = 0 lanes: afterwards the low
@@ -487,6 +494,9 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         asm volatile("" : "+v"(upc));
                         const bool on = upc >= 0;
                         const int j = upc & 255, c16 = (upc >> 8) << 4;
+                        if constexpr (SMASK)
+                            um[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_ms, on ? (pixl + j) * (a.upsum_c >> 3) + (x.m_base >> 3) + (c16 >> 4) : (int)0x80000000, 0, 0);
+                        else
                         um[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, on ? ((pixl + j) * a.upsum_mask.cs + a.upsum_mask.co + x.m_base) * 2 + c16 : (int)0x80000000, 0, 0);
                     }
 #pragma unroll
@@ -505,7 +515,9 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         u32x4_t r;
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
-                            const int mlo = (int)(short)(um[k][q] & 0xffffu), mhi = (int)um[k][q] >> 16;
+                            int mlo, mhi;
+                            if constexpr (SMASK) { mlo = (um[k][0] >> (2 * q)) & 1u; mhi = (um[k][0] >> (2 * q + 1)) & 1u; }
+                            else { mlo = (int)(short)(um[k][q] & 0xffffu); mhi = (int)um[k][q] >> 16; }
                             r[q] = pack_bf16x2(sum[2 * q] * (mlo > 0 ? 1.f : LRELU_SLOPE), sum[2 * q + 1] * (mhi > 0 ? 1.f : LRELU_SLOPE));
                         }
                         __builtin_amdgcn_raw_buffer_store_b128(r, rs_up, on ? ((pixl + j) * a.upsum.cs + a.upsum.co + x.m_base) * 2 + c16 : (int)0x80000000, 0, 0);
@@ -533,7 +545,9 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                             if constexpr (HAS_MASK) {
                                 // LeakyReLU'(saved fp16 activation): slope where it is <= 0 (sign test on the raw halves: the
                                 // activation is > 0 iff its bits, read as a signed 16-bit integer, are > 0; NaN never occurs)
-                                const int mlo = (int)(short)(mb[k][q] & 0xffffu), mhi = (int)mb[k][q] >> 16;
+                                int mlo, mhi;
+                                if constexpr (SMASK) { mlo = (mb[k][0] >> (2 * q)) & 1u; mhi = (mb[k][0] >> (2 * q + 1)) & 1u; }
+                                else { mlo = (int)(short)(mb[k][q] & 0xffffu); mhi = (int)mb[k][q] >> 16; }
                                 v0 *= mlo > 0 ? 1.f : LRELU_SLOPE;
                                 v1 *= mhi > 0 ? 1.f : LRELU_SLOPE;
                             }
@@ -541,8 +555,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         }
                     }
                     __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
-                    if constexpr (UROT) {
-                        if (a.urot_smask) {      // sign byte of the piece: bit q = (channel q > 0), on the raw fp16 halves
+                    if constexpr (UROT || SOUT) {
+                        if (SOUT || a.urot_smask) {      // sign byte of the piece: bit q = (channel q > 0), on the raw fp16 halves
                             unsigned sb = 0;
 #pragma unroll
                             for (int q = 0; q < 4; ++q)
@@ -605,6 +619,17 @@ bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size) {
     return true;
 }
 
+// LeakyReLU sign bytes (ssdn_conv_args.sign_out / mask_sign / upsum_mask_sign): forward role of one 96-channel block writes them; the
+// data-gradient role reads them for a mask that views a whole tensor of M channels (no skip gradient in the same launch) or for the
+// up-sampled half's mask of the fused UPSUM_BWD (a whole tensor of upsum_c channels)
+bool conv_dma_signs(const ssdn_conv_args* a) {
+    if (!conv_dma_eligible(a, false)) return false;
+    if (a->sign_out && (a->bf16 || !a->dst.p || a->urot.p || a->M != 96 || a->Mpad != 96)) return false;
+    if (a->mask_sign && (!a->bf16 || !a->mask.p || a->add.p || a->upsum.p || a->mask.cs != a->M || a->mask.co != 0 || (a->Mpad != 96 && a->Mpad != 64))) return false;
+    if (a->upsum_mask_sign && (!a->bf16 || !a->upsum.p || a->upsum_mask.cs != a->upsum_c || a->upsum_mask.co != 0)) return false;
+    return true;
+}
+
 int conv_dma_lds_bytes(int mt) { return 2 * CD_TBYTES + 2 * mt * 32 * 96; }
 
 template <int MT, bool BF, int EPI>
@@ -641,14 +666,25 @@ static int cd_launch_role(const ssdn_conv_args* a, const CdAux& x, hipStream_t s
         if constexpr (MT == 3) return cd_launch<3, false, 8>(a, x, s);
         return ssdn_set_error("conv_dma: fused UNROT_FWD needs M = 96");
     }
-    if (!a->bf16) return cd_launch<MT, false, 0>(a, x, s);
+    if (!a->bf16) {
+        if (a->sign_out) {                         // + LeakyReLU sign bytes of the output (conv_dma_signs: one 96-channel block)
+            if constexpr (MT == 3) return cd_launch<3, false, 16>(a, x, s);
+            return ssdn_set_error("conv_dma: sign_out needs M = 96");
+        }
+        return cd_launch<MT, false, 0>(a, x, s);
+    }
     if (a->upsum.p && x.m_base < a->upsum_c) {      // block of up-sampled-input channels: fused UPSUM_BWD (MT = 3 only)
         if constexpr (MT == 3) {
-            if (x.m_base + 96 <= a->upsum_c && x.m_cnt == 96 && !a->mask.p && !a->add.p) return cd_launch<3, true, 4>(a, x, s);
+            if (x.m_base + 96 <= a->upsum_c && x.m_cnt == 96 && !a->mask.p && !a->add.p)
+                return a->upsum_mask_sign ? cd_launch<3, true, 4 | 32>(a, x, s) : cd_launch<3, true, 4>(a, x, s);
         }
         return ssdn_set_error("conv_dma: fused upsum needs whole 96-channel blocks without mask / add");
     }
     const int epi = (a->mask.p ? 1 : 0) | (a->add.p ? 2 : 0);
+    if (a->mask_sign) {                            // LeakyReLU' from sign bytes (conv_dma_signs: mask without add, Mpad 96 or 64)
+        if constexpr (MT >= 2) { if (epi == 1) return cd_launch<MT, true, 1 | 32>(a, x, s); }
+        return ssdn_set_error("conv_dma: mask_sign needs a mask, no skip gradient, Mpad = 96 or 64");
+    }
     switch (epi) {
         case 0: return cd_launch<MT, true, 0>(a, x, s);
         case 1: return cd_launch<MT, true, 1>(a, x, s);

@@ -908,7 +908,10 @@ static bool conv_flat_path(const ssdn_conv_args* a) {
            conv_flat_ok(a, g, a->kc / 16, wide ? 512 : 256);
 }
 bool conv_signs(const ssdn_conv_args* a) {
-    return (a->sign_out || a->mask_sign) && !conv_validate(a) && conv_use_gemm(a) && gemm_dma_signs(a);
+    if (!(a->sign_out || a->mask_sign || a->upsum_mask_sign) || conv_validate(a)) return false;
+    if (conv_use_gemm(a)) return !a->upsum_mask_sign && gemm_dma_signs(a);
+    if (conv_use_thin(a)) return a->sign_out && !a->mask_sign && !a->upsum_mask_sign;       // k_conv_thin writes them (forward only)
+    return conv_use_dma(a) && conv_dma_signs(a);
 }
 bool conv_fuses_urot(const ssdn_conv_args* a) {
     return a->urot.p && !conv_validate(a) && !conv_use_gemm(a) && !conv_use_thin(a) && conv_use_dma(a);   // (conv_dma_eligible checks the shape)
@@ -930,7 +933,7 @@ bool conv_fuses_upsum(const ssdn_conv_args* a) {
 int launch_conv(const ssdn_conv_args* a, hipStream_t s) {
     int rc = conv_validate(a);
     if (rc) return rc;
-    if ((a->sign_out || a->mask_sign) && !conv_signs(a)) return ssdn_set_error("conv: sign bytes requested for a launch that cannot write / read them (ssdn_conv_signs)");
+    if ((a->sign_out || a->mask_sign || a->upsum_mask_sign) && !conv_signs(a)) return ssdn_set_error("conv: sign bytes requested for a launch that cannot write / read them (ssdn_conv_signs)");
     if (a->urot.p && !conv_fuses_urot(a)) return ssdn_set_error("conv: fused UNROT_FWD requested for a launch that cannot fuse it (ssdn_conv_fuses_urot)");
     if (a->unrot.p && !conv_fuses_unrot(a)) return ssdn_set_error("conv: fused UNROT_BWD requested for a launch that cannot fuse it (ssdn_conv_fuses_unrot)");
     if (a->upsum.p && !conv_fuses_upsum(a)) return ssdn_set_error("conv: fused upsum requested for a launch that cannot fuse it (ssdn_conv_fuses_upsum)");

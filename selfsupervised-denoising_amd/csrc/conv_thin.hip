@@ -159,6 +159,13 @@ __global__ __launch_bounds__(CT_THREADS) void k_conv_thin(ssdn_conv_args a, int 
             const int p = e / npc, cc = e - p * npc;
             const u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + (i & 1) * (4 * 32 * OSTR) + p * OSTR + cc * 16);
             *reinterpret_cast<u32x4_t*>(dst + (pix0 + p) * a.dst.cs + cc * 8) = o;
+            if (a.sign_out) {      // LeakyReLU sign byte of the piece (ssdn_conv_args.sign_out): bit q = (channel q > 0), on the raw fp16 halves
+                unsigned sb = 0;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    sb |= ((int)(short)(o[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q) | (((int)o[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                ((unsigned char*)a.sign_out)[(pix0 + p) * npc + cc] = (unsigned char)sb;
+            }
         }
     }
 }

@@ -59,9 +59,11 @@ __global__ void k_pool_fwd(ssdn_pool_args a) {
     int n = p / (unsigned)(Wo * Ho);
     const h16* src = (const h16*)a.act.p + a.act.co + c;
     int r0 = a.shifted ? 2 * i - 1 : 2 * i;
+    const bool padrow = a.shifted && r0 < 0;
     float m[8];
+    unsigned win[8];       // route nibble of the channel: bits 0-1 = window position of the first maximum, bit 2 = the zero pad row holds it
 #pragma unroll
-    for (int q = 0; q < 8; ++q) m[q] = (a.shifted && r0 < 0) ? 0.f : -65504.f;  // literal zero row takes part
+    for (int q = 0; q < 8; ++q) { m[q] = padrow ? 0.f : -65504.f; win[q] = 4u; }  // literal zero row takes part (and is scanned first)
 #pragma unroll
     for (int dr = 0; dr < 2; ++dr) {
         int y = r0 + dr;
@@ -70,13 +72,25 @@ __global__ void k_pool_fwd(ssdn_pool_args a) {
         for (int dc = 0; dc < 2; ++dc) {
             half8 v = ld_h8(src + (((long long)n * a.H + y) * a.W + 2 * j + dc) * a.act.cs);
 #pragma unroll
-            for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (float)v[q]);
+            for (int q = 0; q < 8; ++q) {
+                const float f = (float)v[q];
+                // (first maximum in scan order: a later position only takes over when strictly greater; the first real position always
+                //  takes over from the -65504 start value of an un-padded window, where no activation is smaller)
+                if (f > m[q] || (!padrow && dr == 0 && dc == 0)) win[q] = (unsigned)(2 * dr + dc);
+                m[q] = fmaxf(m[q], f);
+            }
         }
     }
     half8 o;
 #pragma unroll
     for (int q = 0; q < 8; ++q) o[q] = (h16)m[q];
     st_h8((h16*)a.pooled.p + a.pooled.co + c + (((long long)n * Ho + i) * Wo + j) * a.pooled.cs, o);
+    if (a.route) {         // + bit 3 = the winner is > 0 (LeakyReLU' = 1): everything SSDN_OP_POOL_BWD needs of `act`
+        unsigned r = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) r |= (win[q] | (m[q] > 0.f ? 8u : 0u)) << (4 * q);
+        ((unsigned*)a.route)[idx] = r;
+    }
 }
 int launch_pool_fwd(const ssdn_pool_args* a, hipStream_t s) {
     if ((a->C & 7) || (a->H & 1) || (a->W & 1)) return ssdn_set_error("pool: C%%8, H%%2, W%%2 must be 0");
@@ -100,6 +114,29 @@ __global__ void k_pool_bwd(ssdn_pool_args a) {
     unsigned short* dz = (unsigned short*)a.dz.p + a.dz.co + c;                     // gradients are bf16
     u16x8 g = ld_b8((const unsigned short*)a.dpool.p + a.dpool.co + c + (((long long)n * Ho + i) * Wo + j) * a.dpool.cs);
     int r0 = a.shifted ? 2 * i - 1 : 2 * i;
+    if (a.route) {
+        // the forward pass left the route word of this (window, 8 channels): winner position, "the pad row won", winner > 0 -- the
+        // same decisions the scan below takes from `act` (bit-identical), for 4 bytes instead of 64
+        const unsigned r = ((const unsigned*)a.route)[idx];
+        float gs[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) gs[q] = bf2f(g[q]) * (((r >> (4 * q)) & 8u) ? 1.f : LRELU_SLOPE);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            int y = r0 + (k >> 1);
+            if (y < 0) continue;
+            u16x8 o;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) o[q] = ((r >> (4 * q)) & 7u) == (unsigned)k ? f2bf(gs[q]) : (unsigned short)0;
+            st_b8(dz + (((long long)n * a.H + y) * a.W + 2 * j + (k & 1)) * a.dz.cs, o);
+        }
+        if (a.shifted && i == Ho - 1) {
+            u16x8 z = zero_b8();
+            st_b8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j) * a.dz.cs, z);
+            st_b8(dz + (((long long)n * a.H + a.H - 1) * a.W + 2 * j + 1) * a.dz.cs, z);
+        }
+        return;
+    }
     half8 v[4];
     float m[8];
     bool taken[8];

@@ -343,7 +343,8 @@ class DeviceNet:
             s.unrot_smask = self.t[a["unrot_smask"]].data_ptr() if a.get("unrot_smask") else None
             s.sign_out = self.t[a["sign_out"]].data_ptr() if a.get("sign_out") else None
             s.mask_sign = self.t[a["mask_sign"]].data_ptr() if a.get("mask_sign") else None
-            if (a.get("sign_out") or a.get("mask_sign")) and not L.load().ssdn_conv_signs(C.byref(s)):
+            s.upsum_mask_sign = self.t[a["upsum_mask_sign"]].data_ptr() if a.get("upsum_mask_sign") else None
+            if (a.get("sign_out") or a.get("mask_sign") or a.get("upsum_mask_sign")) and not L.load().ssdn_conv_signs(C.byref(s)):
                 raise L.SsdnHipError("conv %s: the plan uses sign bytes but the library cannot (planner / library rule mismatch)" % a["layer"])
             s.urot = self._view(a.get("urot"))
             s.urot_smask = self.t[a["urot_smask"]].data_ptr() if a.get("urot_smask") else None
@@ -356,7 +357,8 @@ class DeviceNet:
             return op.type, s
         if op.type in ("pool_fwd", "pool_bwd"):
             return op.type, L.PoolArgs(self._view(a["act"]), self._view(a.get("pooled")), self._view(a.get("dpool")),
-                                       self._view(a.get("dz")), a["N"], a["H"], a["W"], a["C"], a["shifted"])
+                                       self._view(a.get("dz")), a["N"], a["H"], a["W"], a["C"], a["shifted"],
+                                       self.t[a["route"]].data_ptr() if a.get("route") else None)
         if op.type == "upsum_bwd":
             return op.type, L.UpsumArgs(self._view(a["src"]), self._view(a["mask"]), self._view(a["dst"]), a["N"], a["H"], a["W"], a["C"])
         if op.type in ("unrot_fwd", "unrot_bwd"):

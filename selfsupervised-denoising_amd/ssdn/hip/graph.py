@@ -31,6 +31,8 @@ WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient 
 WGRAD_MEGA = "split"
 FUSE_UNROT_FWD = True         # decode_block_1.2 stores its output un-rotated (no SSDN_OP_UNROT_FWD launch, no d1b tensor) where k_cdma serves it
 SIGN_BYTES_HEAD = True        # output_block.0 leaves sign bytes of its 384-channel output for the data gradient of output_block.2
+POOL_ROUTE = True             # SSDN_OP_POOL_FWD leaves route words (winner position + LeakyReLU sign); a stand-alone SSDN_OP_POOL_BWD reads them instead of the activation
+SIGN_BYTES_CONV = True        # the 3x3 layers k_cdma / k_conv_thin serve leave sign bytes of their outputs; k_cdma's data gradients read them as LeakyReLU' masks
 SIGN_BYTES = True             # the fused un-rotation of the backward pass reads LeakyReLU sign bytes (12 B/pixel) instead of d1b (192 B/pixel)
 MEGA_MIN_PX = 32768           # networks with fewer pixels (N*H*W) at full resolution keep the per-layer launches: a handful of tiles per
                               # layer is latency, not throughput (config 1's shape, batch 4 at 32x32: 0.66 ms per step vs 0.70 / 0.77)
@@ -325,11 +327,13 @@ class NetPlan:
 
     def _conv(self, lst, layer: Layer, role: str, src0, c0, up0, src1, c1, N, H, W, taps, M, dst=None, dst32=None,
               bias=True, act=True, mask=None, add=None, pool=None, pool_shifted=0, upsum=None, upsum_mask=None, upsum_c=0,
-              unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None, sign_out=None, mask_sign=None):
+              unrot=None, unrot_mask=None, unrot_smask=None, urot=None, urot_smask=None, sign_out=None, mask_sign=None, upsum_mask_sign=None):
         """pool: view of the pooled tensor -- the conv's epilogue also writes Shift2d + MaxPool2d(2) of its output
         (ssdn_conv_args.pool).  Returns True if the pool was fused (the caller then emits no SSDN_OP_POOL_FWD)."""
         Ktot = c0 + c1
         Mpad = ceil_to(M, 32)
+        if upsum is None:
+            upsum_mask_sign = None
         ltw, lth, ltn, kc = choose_conv_tile(N, H, W, taps, Ktot, Mpad, out16=dst32 is None, cus=self.cus)
         fused = pool is not None and conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus)
         if upsum is not None:
@@ -340,6 +344,8 @@ class NetPlan:
                 mask is None and add is None
             if not fused:
                 upsum = upsum_mask = None
+            if not (fused and dma):
+                upsum_mask_sign = None      # (only k_cdma reads the up-sampled half's mask as sign bytes)
         lst.append(Op("conv", dict(layer=layer.name, role=role, src0=src0, src1=src1, c0=c0, c1=c1, up0=int(up0), N=N, H=H, W=W,
                                    taps=list(taps), M=M, Mpad=Mpad, Ktot=Ktot, bias=bias, act=int(act), mask=mask, add=add,
                                    dst=dst, dst32=dst32, ltw=ltw, lth=lth, ltn=ltn, kc=kc, bf16=int(role == "dgrad"),
@@ -348,7 +354,8 @@ class NetPlan:
                                    pool_shifted=int(pool_shifted) if (fused and pool is not None) else 0,
                                    upsum=upsum, upsum_mask=upsum_mask, upsum_c=int(upsum_c) if upsum is not None else 0,
                                    unrot=unrot, unrot_mask=unrot_mask, unrot_smask=unrot_smask,
-                                   urot=urot, urot_smask=urot_smask, sign_out=sign_out, mask_sign=mask_sign)))
+                                   urot=urot, urot_smask=urot_smask, sign_out=sign_out, mask_sign=mask_sign,
+                                   upsum_mask_sign=upsum_mask_sign)))
         return fused
 
     def _wgrad(self, layer: Layer, dz: View, Mz: int, src0, c0, up0, src1, c1, cin_real, N, H, W, taps,
@@ -476,21 +483,43 @@ class NetPlan:
         f.append(Op("pack_input", dict(src=self.prefix + "in32", dst=View(x16), B=B, C=C, H=H, W=W, R=self.R, cpad=32)))
 
         fused_pool = {}
+        # LeakyReLU sign bytes (one byte per 8 channels) of the activations whose only use in the backward pass, besides being a
+        # weight-gradient operand, is the LeakyReLU' mask of a k_cdma data gradient: activation tensor -> sign tensor.  The producers that
+        # can write them: k_cdma on one 96-channel block, k_conv_thin (csrc/conv_dma.hip::conv_dma_signs, csrc/conv_mfma.hip::conv_signs;
+        # the engine cross-checks every launch with ssdn_conv_signs)
+        signs = self.signs = {}
 
-        def enc(name, lname, src, cin_slots, h, w, pool_name=None):
+        def cdma_serves(h, w, ktot):
+            """csrc/conv_dma.hip::conv_dma_eligible for the 3x3 layers of this network at h x w"""
+            return h % 16 == 0 and w % 16 == 0 and N * (h // 16) * (w // 16) >= self.dev_cus and ktot % 48 in (0, 16)
+
+        def sign_of(t, h, w, C_, ktot_fwd, thin=False):
+            ok = self.train and SIGN_BYTES_CONV and cdma_serves(h, w, C_) and \
+                ((thin and 1 <= C <= 3 and w % 64 == 0) or (not thin and C_ == 96 and cdma_serves(h, w, ktot_fwd)))
+            if ok:
+                signs[t] = self.T("smk_" + t[len(self.prefix):], "u8", (N, h, w, C_ // 8))
+            return signs.get(t)
+
+        def enc(name, lname, src, cin_slots, h, w, pool_name=None, sign=False):
             t = self.act(name, N, h, w, 48)
             pv = View(self.act(pool_name, N, h // 2, w // 2, 48)) if pool_name else None
             fused_pool[name] = self._conv(f, L[lname], "fwd", View(src), cin_slots, 0, None, 0, N, h, w, t3, 48, dst=View(t),
-                                          pool=pv, pool_shifted=int(bs))
+                                          pool=pv, pool_shifted=int(bs), sign_out=sign_of(t, h, w, 48, cin_slots, thin=True) if sign else None)
             return t
+
+        routes = self.routes = {}      # full-resolution activation -> route words of its max-pool (ssdn_pool_args.route)
 
         def pool(name, src, h, w):
             t = self.act(name, N, h // 2, w // 2, 48)
             if not fused_pool.get(src[len(self.prefix):]):        # (else: written by the producing conv's epilogue)
-                f.append(Op("pool_fwd", dict(act=View(src), pooled=View(t), N=N, H=h, W=w, C=48, shifted=int(bs))))
+                # route words where the backward op runs on its own (pooled images of > 256 pixels: smaller ones ride in k_conv_chain,
+                # which reads the activation planes it holds in LDS anyway)
+                if self.train and POOL_ROUTE and (h // 2) * (w // 2) > 256:
+                    routes[src] = self.T("route_" + name, "u32", (N, h // 2, w // 2, 48 // 8))
+                f.append(Op("pool_fwd", dict(act=View(src), pooled=View(t), N=N, H=h, W=w, C=48, shifted=int(bs), route=routes.get(src))))
             return t
 
-        e0 = enc("e0", "encode_block_1.0", x16, 16, H, W)
+        e0 = enc("e0", "encode_block_1.0", x16, 16, H, W, sign=True)      # (mask of encode_block_1.2's data gradient)
         e1 = enc("e1", "encode_block_1.2", e0, 48, H, W, "p1")
         p1 = pool("p1", e1, H, W)
         e2 = enc("e2", "encode_block_2.0", p1, 48, H // 2, W // 2, "p2")
@@ -505,12 +534,15 @@ class NetPlan:
 
         def dec(name_a, name_b, la, lb, up_src, c_up, skip, c_skip, h, w, urot=None, urot_smask=None):
             ta = self.act(name_a, N, h, w, 96)
-            self._conv(f, L[la], "fwd", View(up_src), c_up, 1, View(skip), c_skip, N, h, w, t3, 96, dst=View(ta))
+            self._conv(f, L[la], "fwd", View(up_src), c_up, 1, View(skip), c_skip, N, h, w, t3, 96, dst=View(ta),
+                       sign_out=sign_of(ta, h, w, 96, c_up + c_skip))       # (mask of the second conv's data gradient)
             if urot is not None:      # the second conv stores un-rotated (fused SSDN_OP_UNROT_FWD): its own output tensor never exists
                 self._conv(f, L[lb], "fwd", View(ta), 96, 0, None, 0, N, h, w, t3, 96, dst=None, urot=View(urot), urot_smask=urot_smask)
                 return ta, None
             tb = self.act(name_b, N, h, w, 96)
-            self._conv(f, L[lb], "fwd", View(ta), 96, 0, None, 0, N, h, w, t3, 96, dst=View(tb))
+            # (mask of the up-sampled half in the next stage's data gradient -- where that one is a k_cdma launch with the fused UPSUM_BWD)
+            self._conv(f, L[lb], "fwd", View(ta), 96, 0, None, 0, N, h, w, t3, 96, dst=View(tb),
+                       sign_out=sign_of(tb, h, w, 96, 96) if cdma_serves(2 * h, 2 * w, 96) and 2 * h <= H else None)
             return ta, tb
 
         d5a, d5b = dec("d5a", "d5b", "decode_block_5.0", "decode_block_5.2", e6, 48, p4, 48, H // 16, W // 16)
@@ -615,7 +647,7 @@ class NetPlan:
             """backward of conv_b(conv_a(cat(up(up_src), skip))); returns (g_up_src, view of the skip gradient)."""
             self._wgrad(L[lb], View(g_tb), 96, View(ta), 96, 0, None, 0, 96, N, h, w, t3)
             g_ta = self.grad("g_" + tag + "a", N, h, w, 96)
-            dgrad(lb, g_tb, 96, N, h, w, rt3, 96, View(g_ta), mask=View(ta))
+            dgrad(lb, g_tb, 96, N, h, w, rt3, 96, View(g_ta), mask=View(ta), mask_sign=signs.get(ta))
             # one input tensor per weight-gradient launch (the kernel's row loads have one base address)
             self._wgrad(L[la], View(g_ta), 96, View(up_src), c_up, 1, None, 0, c_up, N, h, w, t3, c_off=0, with_bias=True)
             self._wgrad(L[la], View(g_ta), 96, None, 0, 0, View(skip), c_skip, c_skip_real, N, h, w, t3, c_off=c_up, with_bias=False)
@@ -623,7 +655,8 @@ class NetPlan:
             dxs = self.grad("dxs_" + tag, N, h, w, Mx)
             g_up = self.grad("g_up_" + tag, N, h // 2, w // 2, c_up)
             # (the 2x2 sum + LeakyReLU' of the up-sampled half is fused into the data-gradient conv where the library can)
-            if not dgrad(la, g_ta, 96, N, h, w, rt3, Mx, View(dxs), upsum=View(g_up), upsum_mask=View(up_src), upsum_c=c_up):
+            if not dgrad(la, g_ta, 96, N, h, w, rt3, Mx, View(dxs), upsum=View(g_up), upsum_mask=View(up_src), upsum_c=c_up,
+                         upsum_mask_sign=signs.get(up_src)):
                 b.append(Op("upsum_bwd", dict(src=View(dxs), mask=View(up_src), dst=View(g_up), N=N, H=h // 2, W=w // 2, C=c_up)))
             return g_up, (View(dxs, c_up) if need_skip_grad else None)
 
@@ -640,7 +673,8 @@ class NetPlan:
             g_p = self.grad("g_p_" + tag, N, h, w, 48)
             dgrad(lname, g_out, 48, N, h, w, rt3, 48, View(g_p), add=skip_add)
             g_prev = self.grad("g_e_" + tag, N, 2 * h, 2 * w, 48)
-            b.append(Op("pool_bwd", dict(act=View(act_prev), dpool=View(g_p), dz=View(g_prev), N=N, H=2 * h, W=2 * w, C=48, shifted=int(bs))))
+            b.append(Op("pool_bwd", dict(act=View(act_prev), dpool=View(g_p), dz=View(g_prev), N=N, H=2 * h, W=2 * w, C=48, shifted=int(bs),
+                                         route=routes.get(act_prev))))
             return g_prev
 
         g_e5 = enc_bwd("encode_block_6.0", g_e6, p5, H // 32, W // 32, "6", None, e5)
@@ -651,7 +685,7 @@ class NetPlan:
         # encode_block_1.2 (e0 -> e1) and encode_block_1.0 (x16 -> e0)
         self._wgrad(L["encode_block_1.2"], View(g_e1), 48, View(e0), 48, 0, None, 0, 48, N, H, W, t3)
         g_e0 = self.grad("g_e0", N, H, W, 48)
-        dgrad("encode_block_1.2", g_e1, 48, N, H, W, rt3, 48, View(g_e0), mask=View(e0))
+        dgrad("encode_block_1.2", g_e1, 48, N, H, W, rt3, 48, View(g_e0), mask=View(e0), mask_sign=signs.get(e0))
         self._wgrad(L["encode_block_1.0"], View(g_e0), 48, None, 0, 0, View(x16), 16, C, N, H, W, t3)
         if getattr(self, "_mega_ops", None):
             self._plan_mega()

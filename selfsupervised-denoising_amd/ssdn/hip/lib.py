@@ -39,12 +39,12 @@ class ConvArgs(C.Structure):
                 ("ltw", i32), ("lth", i32), ("ltn", i32), ("kc", i32), ("bf16", i32), ("wc", vp), ("kreal", i32),
                 ("pool", View), ("pool_shifted", i32), ("upsum", View), ("upsum_mask", View), ("upsum_c", i32),
                 ("unrot", View), ("unrot_mask", View), ("unrot_smask", vp),
-                ("urot", View), ("urot_smask", vp), ("sign_out", vp), ("mask_sign", vp)]
+                ("urot", View), ("urot_smask", vp), ("sign_out", vp), ("mask_sign", vp), ("upsum_mask_sign", vp)]
 
 
 class PoolArgs(C.Structure):
     _fields_ = [("act", View), ("pooled", View), ("dpool", View), ("dz", View), ("N", i32), ("H", i32), ("W", i32),
-                ("C", i32), ("shifted", i32)]
+                ("C", i32), ("shifted", i32), ("route", vp)]
 
 
 class UpsumArgs(C.Structure):
@@ -128,7 +128,7 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
                  mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, metrics=MetricsArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 12      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 13      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",

@@ -129,8 +129,11 @@ def _out_of(op):
 # conv_mode (last field): 1 = the library's default kernel choice; 2 = the persistent LDS-DMA kernel k_cdma for every 3x3
 # layer of its shape class (>= 16x16 pixels), which by default only serves layers with >= 1 tile per CU (BASELINE sizes)
 # (3, 9, True, 4, 64, 0, 1): 256 16x16 tiles at full resolution = one per CU of an MI355X, from where on decode_block_1.2 stores its output
-# un-rotated (fused SSDN_OP_UNROT_FWD in k_cdma) and the data gradients of the 64x64 stage fuse SSDN_OP_UPSUM_BWD
-CASES = [(3, 9, True, 2, 32, 0, 1), (1, 2, True, 1, 32, 0, 1), (3, 9, True, 4, 64, 0, 1), (3, 3, False, 2, 32, 0, 1), (3, 9, True, 1, 64, 0, 1), (3, 1, False, 2, 64, 0, 1),
+# un-rotated (fused SSDN_OP_UNROT_FWD in k_cdma) and the data gradients of the 64x64 stage fuse SSDN_OP_UPSUM_BWD; k_conv_thin and k_cdma
+# leave LeakyReLU sign bytes of e0 / d1a and the data gradients of encode_block_1.2 / decode_block_1.2 read them (ssdn_conv_args.sign_out /
+# mask_sign).  (3, 9, True, 16, 64, 0, 1): one tile per CU at the 32x32 stage too -- sign bytes of d2a / d2b, the fused UPSUM_BWD of
+# decode_block_1.0's data gradient reads its mask as sign bytes (upsum_mask_sign)
+CASES = [(3, 9, True, 2, 32, 0, 1), (1, 2, True, 1, 32, 0, 1), (3, 9, True, 4, 64, 0, 1), (3, 9, True, 16, 64, 0, 1), (3, 3, False, 2, 32, 0, 1), (3, 9, True, 1, 64, 0, 1), (3, 1, False, 2, 64, 0, 1),
          (3, 9, True, 8, 32, 0, 1), (3, 9, True, 2, 32, 8, 1), (3, 3, False, 2, 64, 6, 1),
          (3, 9, True, 2, 32, 0, 2), (1, 2, True, 1, 32, 0, 2), (3, 3, False, 2, 64, 0, 2), (3, 9, True, 3, 64, 0, 2), (3, 1, False, 5, 32, 0, 2)]
 
@@ -223,6 +226,8 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
         smk = op.a.get("smask") if op.type == "unrot_fwd" else ((op.a.get("urot_smask") or op.a.get("sign_out")) if op.type == "conv" else None)
         if smk is not None:
             dn.t[smk].fill_(0xA5)
+        if op.type == "pool_fwd" and op.a.get("route"):
+            dn.t[op.a["route"]].fill_(-1)
         OpList([rec]).run(current_stream())
         torch.cuda.synchronize()
         if op.type == "conv" and op.a.get("urot") is not None:
@@ -256,6 +261,11 @@ def test_every_op_teacher_forced(cin, cout, bs, B, P, cus_plan, conv_mode, conv_
             if not bool((gots[:, -1] == 0xA5).all()):
                 failures.append("op %d %s: sign bytes of the cut-off row were written" % (i, op.type))
             dn.t[smk].copy_(it.t[smk])
+        if op.type == "pool_fwd" and op.a.get("route"):
+            # route words of the max-pool (ssdn_pool_args.route): exact -- the op's input is the forced one
+            gotr = dn.t[op.a["route"]].cpu().to(torch.int64) & 0xffffffff
+            if not torch.equal(gotr, it.t[op.a["route"]]):
+                failures.append("op %d pool_fwd: %d route words differ" % (i, int((gotr != it.t[op.a["route"]]).sum())))
         if pv is not None:
             # fused max-pool: exactly SSDN_OP_POOL_FWD of what the launch itself stored (max is exact on the rounded values)
             mine = dn.t[dst.t][..., dst.co:dst.co + ch].float().cpu()
