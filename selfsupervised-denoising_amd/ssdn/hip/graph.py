@@ -37,8 +37,9 @@ SIGN_BYTES = True             # the fused un-rotation of the backward pass reads
 MEGA_MIN_PX = 32768           # networks with fewer pixels (N*H*W) at full resolution keep the per-layer launches: a handful of tiles per
                               # layer is latency, not throughput (config 1's shape, batch 4 at 32x32: 0.66 ms per step vs 0.70 / 0.77)
 SPLIT_HEAD_CUS = (1, 2)       # "split": share of the CUs the side-lane launch is planned for
-SPLIT_AFTER = None            # "split": the side-lane launch is issued behind this layer's data gradient; None = as soon as the group's last operand exists
-                              # (measured, same process: behind decode_block_2.0's data gradient 1.6028 ms per step, behind decode_block_2.2's 1.5892, None 1.5864)
+SPLIT_AFTER = "decode_block_2.2"   # "split": the side-lane launch is issued behind this layer's data gradient; None = as soon as the group's last operand exists
+                              # (measured, same process: behind decode_block_2.0's data gradient 1.6028 ms per step, behind decode_block_2.2's 1.5892, None 1.5864;
+                              #  behind decode_block_2.2 only ONE of the eight k_cdma<3,*> launches of a step runs beside it, with None two)
 SPLIT_GROUP0 = ("output_block", "decode_block_2.2")   # "split": layers (name prefixes) of the side-lane launch
 # cost model of one weight-gradient block, in cycles (calibrated on BASELINE config 2 with tools/wgrad_calib.py):
 #   K-step of 16 pixels = base + per_mfma * MT * CPW;  a block = tiles * ksteps * K-step + fixed + slab bytes / slab_rate
