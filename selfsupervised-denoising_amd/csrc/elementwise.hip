@@ -441,9 +441,12 @@ static __device__ __forceinline__ void wreduce_final(const ssdn_wreduce_args& a,
     float inv = a.inv_scale ? *a.inv_scale : 1.f;
     if (idx < stride4) {
         const long long e0 = idx * 4;
-        int k = e0 % a.Kpad;
-        int m = (e0 / a.Kpad) % a.Mpad;
-        int t = e0 / ((long long)a.Kpad * a.Mpad);
+        // (32-bit index arithmetic: a slab has < 2^31 elements -- the launcher's grids are ints; three 64-bit divisions per thread were
+        //  most of this kernel's instructions)
+        const unsigned e32 = (unsigned)e0, row = e32 / (unsigned)a.Kpad;
+        int k = (int)(e32 - row * (unsigned)a.Kpad);
+        int t = (int)(row / (unsigned)a.Mpad);
+        int m = (int)(row - (unsigned)t * (unsigned)a.Mpad);
         const int klim = a.tapblock ? a.Kpad : a.cin;
         if (k < klim && (a.tapblock ? t * a.Kpad + k : k) < a.cin && m < a.M) {
             const float4* p = reinterpret_cast<const float4*>(a.slab + e0);
