@@ -143,3 +143,28 @@ def test_every_baseline_weight_gradient_op_has_an_instance_in_the_chip_wide_laun
         for g, n in blocks.items():
             W = plan.wgrad_group_info(g)[0]
             assert n >= W // 2, "a launch group with far fewer blocks than CUs wastes the chip (%d blocks for %d)" % (n, W)
+
+
+def test_baseline_plan_keeps_sign_bytes_and_route_words_instead_of_activation_reads():
+    """BASELINE config 2's training plan: the producers k_cdma / k_conv_thin / k_gdma serve leave LeakyReLU sign bytes and the
+    data gradients that only need the sign read them (ssdn_conv_args.sign_out / mask_sign / upsum_mask_sign / unrot_smask); the
+    64x64-stage max-pool leaves route words for its stand-alone backward op (ssdn_pool_args.route); an evaluation plan has none."""
+    plan = NetPlan("m/", 3, 9, True, 32, 64, 64, cus=256)
+    conv = lambda ops, role: {op.a["layer"]: op.a for op in ops if op.type == "conv" and op.a["role"] == role}  # noqa: E731
+    f, b = conv(plan.fwd, "fwd"), conv(plan.bwd, "dgrad")
+    for layer, t in (("encode_block_1.0", "m/smk_e0"), ("decode_block_2.0", "m/smk_d2a"), ("decode_block_2.2", "m/smk_d2b"),
+                     ("decode_block_1.0", "m/smk_d1a"), ("output_block.0", "m/smk_na")):
+        assert f[layer]["sign_out"] == t, layer
+        assert plan.tensors[t].kind == "u8"
+    assert f["decode_block_1.2"]["urot"] is not None and f["decode_block_1.2"]["urot_smask"] == "m/smk_d1b"
+    assert b["encode_block_1.2"]["mask_sign"] == "m/smk_e0" and b["decode_block_1.2"]["mask_sign"] == "m/smk_d1a"
+    assert b["decode_block_2.2"]["mask_sign"] == "m/smk_d2a" and b["output_block.2"]["mask_sign"] == "m/smk_na"
+    assert b["decode_block_1.0"]["upsum_mask_sign"] == "m/smk_d2b" and b["decode_block_2.0"].get("upsum_mask_sign") is None
+    assert b["output_block.0"]["unrot_smask"] == "m/smk_d1b"
+    pools = [op.a for op in plan.fwd if op.type == "pool_fwd"]
+    assert [bool(a.get("route")) for a in pools] == [True, False]          # 64x64 -> 32x32 stand-alone; 32x32 -> 16x16: its backward is chained
+    pb = [op.a for op in plan.bwd if op.type == "pool_bwd" and op.a.get("route")]
+    assert len(pb) == 1 and pb[0]["route"] == pools[0]["route"] and pb[0]["H"] == 64
+    ev = NetPlan("m/", 3, 9, True, 2, 512, 512, cus=256, train=False)
+    assert not any(k.startswith("m/smk_") or k.startswith("m/route_") for k in ev.tensors)
+    assert not any(op.a.get("sign_out") or op.a.get("route") for op in ev.fwd)
