@@ -400,7 +400,7 @@ typedef struct ssdn_adam_args {
  * and acc[2k] += sum_b value_k[b], acc[2k+1] += count_k for k = 0..4 = loss, psnr_out, psnr_mu, noise_std, model_std (count = B; 1
  * for a noise_std that is one value for the whole batch) -- exactly what `Metric.add` of the reference accumulates (sum over the
  * samples of the per-sample value, sample count).  Deterministic: per-sample values go through `per`, the block that arrives last
- * (ticket in acc[15]) adds them in sample order.  NULL inputs are skipped. */
+ * (ticket in acc[15]) adds them in a fixed order (deterministic).  NULL inputs are skipped. */
 typedef struct ssdn_metrics_args {
     const float* out;       /* [B,C,H,W] or NULL */
     const float* mu;        /* [B,C,H,W] or NULL */

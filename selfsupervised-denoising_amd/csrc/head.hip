@@ -326,31 +326,70 @@ int launch_mse(const ssdn_mse_args* a, int masked, hipStream_t s) {
     return 0;
 }
 
-// H11 (SSDN_OP_METRICS): one block per sample; the block that arrives last adds the per-sample values in sample order
-__global__ void k_metrics(ssdn_metrics_args a) {
-    __shared__ float sh[4];
+// H11 (SSDN_OP_METRICS): one block per sample; the block that arrives last adds the per-sample values in a fixed order
+#define MB 1024          // threads of a k_metrics block: 16 waves (a sample is C*H*W = 12288 elements at BASELINE sizes: 12 per thread)
+static __device__ __forceinline__ float metrics_block_sum(float v, float* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) sh[w] = v;
+    __syncthreads();
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < MB / 64; ++k) t += sh[k];
+    return t;
+}
+__global__ __launch_bounds__(MB) void k_metrics(ssdn_metrics_args a) {
+    __shared__ float sh[MB / 64];
     __shared__ int last;
     const int b = blockIdx.x;
     const int HW = a.H * a.W;
     const int e1 = a.ext ? a.ext[2 * b] : a.H, e2 = a.ext ? a.ext[2 * b + 1] : a.W;
+    const bool crop = e1 < a.H || e2 < a.W;      // (block-uniform: the coordinates of an element are only needed for a cropped extent)
     float so = 0.f, sm = 0.f, ss = 0.f, sn = 0.f;
     const long long base = (long long)b * a.C * HW;
-    for (int i = threadIdx.x; i < a.C * HW; i += HB) {
-        const int p = i % HW, y = p / a.W, x = p - y * a.W;
-        if (y >= e1 || x >= e2) continue;
-        const float c = a.clean[base + i];
-        if (a.out) { const float d = a.out[base + i] - c; so += d * d; }
-        if (a.mu) { const float d = a.mu[base + i] - c; sm += d * d; }
+    // (the trainer's kernel trace showed this launch at 50 us per step: 256 threads per sample, one element -- three loads and two
+    //  integer divisions -- at a time.  Now 1024 threads with six elements' loads in flight each)
+    constexpr int UNR = 6;
+    const int n = a.C * HW;
+    for (int i0 = threadIdx.x; i0 < n; i0 += MB * UNR) {
+        float c[UNR], o[UNR], m[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const int i = i0 + u * MB;
+            bool ok = i < n;
+            if (crop) {
+                const int p = i % HW, y = p / a.W, x = p - y * a.W;
+                ok = ok && y < e1 && x < e2;
+            }
+            c[u] = ok ? a.clean[base + i] : 0.f;
+            o[u] = (ok && a.out) ? a.out[base + i] : c[u];
+            m[u] = (ok && a.mu) ? a.mu[base + i] : c[u];
+        }
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+            const float d0 = o[u] - c[u], d1 = m[u] - c[u];
+            so += d0 * d0;
+            sm += d1 * d1;
+        }
     }
-    if (a.model_std)
-        for (int i = threadIdx.x; i < HW; i += HB) ss += a.model_std[(long long)b * HW + i];
     const bool npix = a.noise_std && a.noise_n == a.B * HW;
-    if (npix)
-        for (int i = threadIdx.x; i < HW; i += HB) sn += a.noise_std[(long long)b * HW + i];
-    so = block_sum(so, sh); __syncthreads();
-    sm = block_sum(sm, sh); __syncthreads();
-    ss = block_sum(ss, sh); __syncthreads();
-    sn = block_sum(sn, sh);
+    for (int i0 = threadIdx.x; i0 < HW; i0 += MB * 4) {
+        float v[4], w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * MB;
+            v[u] = (a.model_std && i < HW) ? a.model_std[(long long)b * HW + i] : 0.f;
+            w[u] = (npix && i < HW) ? a.noise_std[(long long)b * HW + i] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { ss += v[u]; sn += w[u]; }
+    }
+    so = metrics_block_sum(so, sh); __syncthreads();
+    sm = metrics_block_sum(sm, sh); __syncthreads();
+    ss = metrics_block_sum(ss, sh); __syncthreads();
+    sn = metrics_block_sum(sn, sh);
     if (threadIdx.x == 0) {
         const float cnt = (float)a.C * (float)e1 * (float)e2;
         float* q = a.per + 8 * b;
@@ -364,25 +403,41 @@ __global__ void k_metrics(ssdn_metrics_args a) {
         last = t == (unsigned)a.B - 1;
     }
     __syncthreads();
-    if (last && threadIdx.x < 5) {
+    if (last && threadIdx.x < 64) {
+        // the first wave of the last block: lane l fetches the five values of samples l, l + 64, ... (all loads independent -- one thread
+        // per metric walking the samples was a chain of B dependent L2 round trips: 32 us at batch 32), then a fixed shuffle tree per metric
         __threadfence();
-        const int k = threadIdx.x;
-        const bool on = k == 0 ? a.loss != nullptr : k == 1 ? a.out != nullptr : k == 2 ? a.mu != nullptr : k == 3 ? a.noise_std != nullptr : a.model_std != nullptr;
-        if (on) {
-            const bool once = k == 3 && a.noise_n == 1;             // one noise level for the whole batch: a single sample of the metric
-            float sum = 0.f;
-            const int nb = once ? 1 : a.B;
-            for (int j = 0; j < nb; ++j) sum += __hip_atomic_load(a.per + 8 * j + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            a.acc[2 * k] += sum;
-            a.acc[2 * k + 1] += (float)nb;
+        const int l = threadIdx.x;
+        float v[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int j = l; j < a.B; j += 64) {
+            float q[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) q[k] = __hip_atomic_load(a.per + 8 * j + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 5; ++k) v[k] += q[k];
         }
-        if (k == 0) *reinterpret_cast<unsigned*>(a.acc + 15) = 0u;
+        const float first3 = __hip_atomic_load(a.per + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // (sample 0's value: the metric of a batch with ONE noise level)
+#pragma unroll
+        for (int k = 0; k < 5; ++k)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_down(v[k], off);
+        if (l == 0) {
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const bool on = k == 0 ? a.loss != nullptr : k == 1 ? a.out != nullptr : k == 2 ? a.mu != nullptr : k == 3 ? a.noise_std != nullptr : a.model_std != nullptr;
+                if (!on) continue;
+                const bool once = k == 3 && a.noise_n == 1;         // one noise level for the whole batch: a single sample of the metric
+                a.acc[2 * k] += once ? first3 : v[k];
+                a.acc[2 * k + 1] += once ? 1.f : (float)a.B;
+            }
+            *reinterpret_cast<unsigned*>(a.acc + 15) = 0u;
+        }
     }
 }
 int launch_metrics(const ssdn_metrics_args* a, hipStream_t s) {
     if (!a->clean || !a->per || !a->acc) return ssdn_set_error("metrics: clean, per and acc must be given");
     if (a->B < 1 || a->C < 1 || a->H < 1 || a->W < 1) return ssdn_set_error("metrics: bad shape");
     if (a->noise_std && a->noise_n != 1 && a->noise_n != a->B && a->noise_n != a->B * a->H * a->W) return ssdn_set_error("metrics: noise_n must be 1, B or B*H*W");
-    hipLaunchKernelGGL(k_metrics, dim3(a->B), dim3(HB), 0, s, *a);
+    hipLaunchKernelGGL(k_metrics, dim3(a->B), dim3(MB), 0, s, *a);
     return 0;
 }
