@@ -328,20 +328,29 @@ int launch_mse(const ssdn_mse_args* a, int masked, hipStream_t s) {
 
 // H11 (SSDN_OP_METRICS): one block per sample; the block that arrives last adds the per-sample values in a fixed order
 #define MB 1024          // threads of a k_metrics block: 16 waves (a sample is C*H*W = 12288 elements at BASELINE sizes: 12 per thread)
-static __device__ __forceinline__ float metrics_block_sum(float v, float* sh) {
+// the four per-sample sums of a block together: wave shuffle trees, one LDS slot per (wave, sum), every thread adds the 16 waves' values in
+// wave order (two barriers for all four instead of two each)
+static __device__ __forceinline__ void metrics_block_sum4(float (&v)[4], float (*sh)[4]) {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[k] += __shfl_down(v[k], o, 64);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
-    __syncthreads();
-    if (l == 0) sh[w] = v;
-    __syncthreads();
-    float t = 0.f;
+    if (l == 0) {
 #pragma unroll
-    for (int k = 0; k < MB / 64; ++k) t += sh[k];
-    return t;
+        for (int k = 0; k < 4; ++k) sh[w][k] = v[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        float t = 0.f;
+#pragma unroll
+        for (int j = 0; j < MB / 64; ++j) t += sh[j][k];
+        v[k] = t;
+    }
 }
 __global__ __launch_bounds__(MB) void k_metrics(ssdn_metrics_args a) {
-    __shared__ float sh[MB / 64];
+    __shared__ float sh[MB / 64][4];
     __shared__ int last;
     const int b = blockIdx.x;
     const int HW = a.H * a.W;
@@ -386,10 +395,9 @@ __global__ __launch_bounds__(MB) void k_metrics(ssdn_metrics_args a) {
 #pragma unroll
         for (int u = 0; u < 4; ++u) { ss += v[u]; sn += w[u]; }
     }
-    so = metrics_block_sum(so, sh); __syncthreads();
-    sm = metrics_block_sum(sm, sh); __syncthreads();
-    ss = metrics_block_sum(ss, sh); __syncthreads();
-    sn = metrics_block_sum(sn, sh);
+    float sums[4] = {so, sm, ss, sn};
+    metrics_block_sum4(sums, sh);
+    so = sums[0]; sm = sums[1]; ss = sums[2]; sn = sums[3];
     if (threadIdx.x == 0) {
         const float cnt = (float)a.C * (float)e1 * (float)e2;
         float* q = a.per + 8 * b;
