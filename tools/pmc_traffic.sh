@@ -26,13 +26,21 @@ def family(k):
     if name.startswith("k_wreduce"): return "k_wreduce*"
     return "elementwise/head/adam"
 res = {}
+perk = {}
+def short(k):
+    k = k.split("(")[0]
+    return k[5:] if k.startswith("void ") else k
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob(out + "/" + c + "/**/*counter_collection.csv", recursive=True)
     acc = collections.defaultdict(list)
+    pk = collections.defaultdict(list)
     for r in csv.DictReader(open(f[0])):
         fam = family(r.get("Kernel_Name", ""))
-        if fam: acc[fam].append(float(r["Counter_Value"]))
+        if fam:
+            acc[fam].append(float(r["Counter_Value"]))
+            pk[short(r["Kernel_Name"])].append(float(r["Counter_Value"]))
     res[c] = acc
+    perk[c] = pk
 fams = sorted(set(res["FETCH_SIZE"]) | set(res["WRITE_SIZE"]))
 nsteps_profiled = None
 table = {}
@@ -56,6 +64,10 @@ j = {"kernel": "k_cdma<3,*> (every launch of the bench workload: decode_block_1.
      "hbm_bytes_per_launch": table.get("k_cdma<3,*>", {}).get("hbm_bytes_per_launch"),
      "fetch_correction": 2.0, "steps_profiled": nst,
      "families": table,
+     "per_kernel_mb_per_launch": {k: {"launches": max(len(perk["FETCH_SIZE"].get(k, [])), len(perk["WRITE_SIZE"].get(k, []))),
+                                      "fetch_x2": round(2.0 * sum(perk["FETCH_SIZE"].get(k, [])) * 1024 / max(1, len(perk["FETCH_SIZE"].get(k, []))) / 1e6, 1),
+                                      "write": round(sum(perk["WRITE_SIZE"].get(k, [])) * 1024 / max(1, len(perk["WRITE_SIZE"].get(k, []))) / 1e6, 1)}
+                                  for k in sorted(set(perk["FETCH_SIZE"]) | set(perk["WRITE_SIZE"]))},
      "total_hbm_mb_per_step": round(sum(t["hbm_mb_per_step"] for t in table.values()), 1),
      "collected_at": "round 4, " + datetime.datetime.utcnow().strftime("%Y-%m-%d %H:%M UTC"),
      "note": "FETCH_SIZE doubled as MI355X_MICROARCH.md (HBM section) prescribes for 16 B/lane coalesced reads on gfx950; WRITE_SIZE as reported (calibrated in round 1 on the weight-gradient slabs). Infinity-Cache hits are counted, not excluded."}
