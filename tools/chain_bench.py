@@ -47,6 +47,25 @@ for on in (0, 1, 0, 1):
     torch.cuda.synchronize()
     print("chain %d: %.2f us per pass" % (on, e0.elapsed_time(e1) * 1e3 / 200))
 
+# cold caches: 768 MB of writes between the passes evict the weights (and everything else) from L2 and the Infinity Cache -- in a training
+# step the chain's weights were written ~0.3 ms and ~0.5 GB of traffic earlier (CHAIN_BENCH_COLD=1)
+if os.environ.get("CHAIN_BENCH_COLD"):
+    junk = torch.empty(768 << 20, dtype=torch.uint8, device=dev)
+    lib.ssdn_conv_set_chain(1)
+    for cold in (0, 1, 0, 1):
+        ts = []
+        for _ in range(30):
+            if cold:
+                junk.fill_(1)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            ol.run(current_stream())
+            e1.record()
+            torch.cuda.synchronize()
+            ts.append(e0.elapsed_time(e1) * 1e3)
+        ts.sort()
+        print("chained, %s caches: median %.2f us per pass (single bracketed launches: includes ~10 us of event overhead)" % ("COLD" if cold else "warm", ts[len(ts) // 2]))
+
 if os.environ.get("SSDN_LIB"):
     lib.ssdn_debug_set_trace.argtypes = [C.c_void_p]
     N = 4 * B
