@@ -31,6 +31,8 @@ WGRAD_CU_FRAC = (3, 4)        # share of the CUs the persistent weight-gradient 
 WGRAD_MEGA = "split"
 FUSE_UNROT_FWD = True         # decode_block_1.2 stores its output un-rotated (no SSDN_OP_UNROT_FWD launch, no d1b tensor) where k_cdma serves it
 SIGN_BYTES_HEAD = True        # output_block.0 leaves sign bytes of its 384-channel output for the data gradient of output_block.2
+X16_SLOTS = 16                # channel slots of the packed network input (C <= 3 real channels): what its readers address (the first layer and
+                              # decode_block_1.0 read a 16-slot chunk, the thin weight gradients the first 8 slots); 32 until round 4: 64-byte pixels
 POOL_ROUTE = True             # SSDN_OP_POOL_FWD leaves route words (winner position + LeakyReLU sign); a stand-alone SSDN_OP_POOL_BWD reads them instead of the activation
 SIGN_BYTES_CONV = True        # the 3x3 layers k_cdma / k_conv_thin serve leave sign bytes of their outputs; k_cdma's data gradients read them as LeakyReLU' masks
 SIGN_BYTES = True             # the fused un-rotation of the backward pass reads LeakyReLU sign bytes (12 B/pixel) instead of d1b (192 B/pixel)
@@ -482,8 +484,8 @@ class NetPlan:
 
         # ---------------- forward ----------------
         self.T("in32", "f32", (B, C, H, W))
-        x16 = self.act("x16", N, H, W, 32)     # C real channels, zero padded to 32 (the first layer reads a 16-channel view)
-        f.append(Op("pack_input", dict(src=self.prefix + "in32", dst=View(x16), B=B, C=C, H=H, W=W, R=self.R, cpad=32)))
+        x16 = self.act("x16", N, H, W, X16_SLOTS)     # C real channels, zero padded (the first layer reads a 16-channel view)
+        f.append(Op("pack_input", dict(src=self.prefix + "in32", dst=View(x16), B=B, C=C, H=H, W=W, R=self.R, cpad=X16_SLOTS)))
 
         fused_pool = {}
         # LeakyReLU sign bytes (one byte per 8 channels) of the activations whose only use in the backward pass, besides being a
@@ -663,7 +665,7 @@ class NetPlan:
                 b.append(Op("upsum_bwd", dict(src=View(dxs), mask=View(up_src), dst=View(g_up), N=N, H=h // 2, W=w // 2, C=c_up)))
             return g_up, (View(dxs, c_up) if need_skip_grad else None)
 
-        g_d2b, _ = dec_bwd("decode_block_1.0", "decode_block_1.2", d1a, d1b, g_d1b, d2b, 96, x16, 32, C, H, W, "d1", need_skip_grad=False)
+        g_d2b, _ = dec_bwd("decode_block_1.0", "decode_block_1.2", d1a, d1b, g_d1b, d2b, 96, x16, X16_SLOTS, C, H, W, "d1", need_skip_grad=False)
         g_d3b, sk_p1 = dec_bwd("decode_block_2.0", "decode_block_2.2", d2a, d2b, g_d2b, d3b, 96, p1, 48, 48, H // 2, W // 2, "d2")
         g_d4b, sk_p2 = dec_bwd("decode_block_3.0", "decode_block_3.2", d3a, d3b, g_d3b, d4b, 96, p2, 48, 48, H // 4, W // 4, "d3")
         g_d5b, sk_p3 = dec_bwd("decode_block_4.0", "decode_block_4.2", d4a, d4b, g_d4b, d5b, 96, p3, 48, 48, H // 8, W // 8, "d4")
