@@ -321,12 +321,18 @@ def run_rank(args):
         prof_kind = L.PROF["cdma_mt3"]
         lib.ssdn_profile_enable(prof_kind, 64 * args.steps // PROF_STRIDE + 64)
         lib.ssdn_profile_set_stride(prof_kind, PROF_STRIDE)
+    # (the collector is off inside the timed region, as in the standard library's timeit: a generation-2 pass of this process takes
+    #  longer than a training step, and the driver's 20-step region is 34 ms)
+    import gc
+    gc.collect()
+    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -339,7 +345,7 @@ def run_rank(args):
     # ---- after the timed region (does not touch `value`) ----------------------------------------------------------------
     # (a) per-family table: every MFMA kernel family bracketed at stride 3 over a few extra steps
     families = {}
-    FAM_STEPS, FAM_STRIDE = 12, 3
+    FAM_STEPS, FAM_STRIDE = 30, 3        # (ten samples of a once-per-step launch: with four, one disturbed sample moved the average by 80 %)
     if lib is not None:
         for name, kind in L.PROF.items():
             lib.ssdn_profile_enable(kind, 80 * FAM_STEPS // FAM_STRIDE + 64)
@@ -445,7 +451,7 @@ def run_rank(args):
                     "frac": round(wg["tflops_algorithmic"] / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "avg_launch_us": wg["avg_launch_us"],
                     "launches_per_step": wg["launches_per_step"],
                     "kernel_time_share": round(wg["ms_per_step_bracketed_sum"] / (1e3 * dt / args.steps), 4),
-                    "sampling": "every 3rd launch of 12 extra steps after the timed region"}
+                    "sampling": "every %d. launch of %d extra steps after the timed region" % (FAM_STRIDE, FAM_STEPS)}
         if resident_value is not None:
             res["value_resident"] = resident_value
             res["value_with_fp32_h2d"] = fp32_value
