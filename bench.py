@@ -309,6 +309,12 @@ def run_rank(args):
         d.train_step(stream.prepare(cur, idx), lr_now(), exchange)
         seen += B * world
 
+    # (the collector is off inside the timed region, as in the standard library's timeit: a generation-2 pass of this process takes
+    #  longer than a training step, and the driver's 20-step region is 34 ms.  Collected BEFORE the warm-up steps, so that the device does
+    #  not sit idle -- and clock down -- between them and the timed region)
+    import gc
+    gc.collect()
+    gc.disable()
     for i in range(args.warmup):
         step(i)
 
@@ -321,11 +327,6 @@ def run_rank(args):
         prof_kind = L.PROF["cdma_mt3"]
         lib.ssdn_profile_enable(prof_kind, 64 * args.steps // PROF_STRIDE + 64)
         lib.ssdn_profile_set_stride(prof_kind, PROF_STRIDE)
-    # (the collector is off inside the timed region, as in the standard library's timeit: a generation-2 pass of this process takes
-    #  longer than a training step, and the driver's 20-step region is 34 ms)
-    import gc
-    gc.collect()
-    gc.disable()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
