@@ -363,6 +363,25 @@ def run_rank(args):
                                   "tflops_algorithmic": round(f2.value / 1e12 / (m2.value / 1e3), 1) if m2.value > 0 else None,
                                   "launches_per_step": round(c2.value * FAM_STRIDE / FAM_STEPS, 1),
                                   "ms_per_step_bracketed_sum": round(m2.value * FAM_STRIDE / FAM_STEPS, 4)}
+    # (a2) N > 1: how long the optimiser stream WAITS for the gradient exchange behind the last slab reduction (events on the compute
+    # stream around launch + finish of ssdn.hip.dp.exchange_step: last k_wreduce_multi -> k_adam_pack), median of EXP_STEPS extra steps
+    exposed = None
+    if exchange is not None:
+        EXP_STEPS = 20
+        exchange.measure_exposed(True)
+        samples = []
+        for i in range(EXP_STEPS):
+            step(i)
+            sync()
+            v = exchange.exposed_us()
+            if v is not None:
+                samples.append(v)
+        exchange.measure_exposed(False)
+        if samples:
+            samples.sort()
+            exposed = {"allreduce_exposed_us": round(samples[len(samples) // 2], 1), "min": round(samples[0], 1), "max": round(samples[-1], 1),
+                       "steps": len(samples), "collectives_per_step_bytes": exchange.unit_bytes(),
+                       "what": "time the optimiser stream waits for the exchange between the last slab reduction and Adam (rank 0)"}
     # (b) side legs (N = 1), >= SIDE_STEPS steps each whatever --steps says: the prepared batch already resident in HBM
     # (kernel-only rate), and the reference's DataLoader format (fp32 noisy + clean from pinned host memory, 2 x 1.6 MB per step)
     resident_value = fp32_value = None
@@ -429,6 +448,8 @@ def run_rank(args):
         }
         if world > 1:
             res["config"]["backend"] = backend or "nccl (RCCL)"
+            res["allreduce_exposed_us"] = exposed["allreduce_exposed_us"] if exposed else None
+            res["allreduce"] = exposed
         if stub:
             res["stub"] = True
             res["data"] = "STUB ENGINE (SSDN_BENCH_STUB=1, CPU dry run of the launcher / exchange / timing protocol): not a measurement"

@@ -205,6 +205,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
             if (!LS && !(LS = lanes_get())) return -1;
             for (int l = 1; l < SSDN_NLANES; ++l) lane_s[l] = LS->side[l];
             for (int src = 0; src < SSDN_NLANES; ++src) {
+                if (ops[i].type == SSDN_OP_EVENT_RECORD) break;      // a mark stands for its OWN lane's work so far, nothing else
                 if (!((g_lane_deps[lane] >> src) & 1) || !dirty[src][lane]) continue;
                 if (!cover_live(src)) {
                     cover_at[src] = LS->ev_next;
@@ -216,9 +217,13 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
                 dirty[src][lane] = false;
             }
         }
-        for (int d = 0; d < SSDN_NLANES; ++d) dirty[lane][d] = true;
+        // (a mark adds no work to its lane: whatever covers the lane's work so far still does)
+        const bool is_mark = ops[i].type == SSDN_OP_EVENT_RECORD;
+        if (!is_mark) {
+            for (int d = 0; d < SSDN_NLANES; ++d) dirty[lane][d] = true;
+            covered[lane] = false;
+        }
         used[lane] = true;
-        covered[lane] = false;
         hipStream_t s = lane_s[lane];
         // arm(j): the op (or merged run) being launched ends at list index j - 1; if the op at j runs on a lane that is ordered after
         // this one, the launch carries a stop event (attaching one to EVERY kernel costs each ~5 us of completion handling)
@@ -237,7 +242,7 @@ int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
         auto arm_last = [&](int j) {
             if (!has_side || no_stop || lane == 0 || armed) return;
             for (; j < n; ++j)
-                if ((one_lane ? 0 : ops[j].lane) == lane) return;
+                if ((one_lane ? 0 : ops[j].lane) == lane && ops[j].type != SSDN_OP_EVENT_RECORD) return;
             armed_at = LS->ev_next;
             g_ssdn_stop_event = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
             g_ssdn_stop_used = false;

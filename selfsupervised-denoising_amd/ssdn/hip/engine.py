@@ -83,41 +83,47 @@ class DeviceNet:
         self.bwd_head = OpList(self._bwd_recs[:len(self._bwd_recs) - len(self.tail_recs)], lanes=True) if self.tail_recs else None
         self.pack = OpList([self._mat(op) for op in plan.pack])
 
-    def bwd_with_events(self, buckets, events):
-        """Backward op list with one SSDN_OP_EVENT_RECORD per gradient bucket, placed on the weight-gradient lane right
-        after the LAST slab reduction of the bucket's layers.  buckets: list of sets of layer names in backward completion
-        order; events: raw hipEvent_t handles (ints), one per bucket.  Used by the overlapped gradient all-reduce
-        (ssdn.hip.dp): the RCCL stream waits for bucket k's event while the backward pass goes on."""
-        last = {}
+    def bwd_with_events(self, buckets, new_event):
+        """Backward op list with SSDN_OP_EVENT_RECORD marks for the gradient exchange (ssdn.hip.dp).  buckets: list of sets of layer
+        names; new_event(bucket indexes) -> raw hipEvent_t handle (int) that the all-reduce of those buckets will wait for.
+        A bucket's slab reductions may run on SEVERAL lanes (plan "split": decode_block_2.2's on the side lane, the rest of its bucket
+        on the main lane, and the executor orders no lane after another before the end-of-list join): the bucket gets one mark per
+        lane, each on that lane right behind the bucket's last reduction THERE, and its collective waits for all of them
+        (one mark on the lane of the last reduction in LIST order left the other lane's writes unordered).
+        Marks that fall on the same (point of the list, lane) share one event."""
+        lane_of = lambda r: r[2] if len(r) > 2 else OpList.LANE.get(r[0], (0,))[0]     # noqa: E731  (what OpList(lanes=True) assigns)
+        last = {}                                              # (bucket, lane) -> index of the bucket's last reduction on that lane
         for i, name in enumerate(self._bwd_layers):
             if name is None:
                 continue
             for k, b in enumerate(buckets):
                 if name in b:
-                    last[k] = i
-        # (a mark inside a run of consecutive reductions would split the run -- the executor merges a run into two launches --: it moves
-        #  to the end of the run; buckets that end in the same run are then marked at the same point)
-        for k in list(last):
-            i = last[k]
-            while i + 1 < len(self._bwd_recs) and self._bwd_recs[i + 1][0] == "wreduce":
+                    last[(k, lane_of(self._bwd_recs[i]))] = i
+        # (a mark inside a run of consecutive reductions of one lane would split the run -- the executor merges a run into two
+        #  launches --: it moves to the end of the run; buckets that end in the same run are then marked at the same point)
+        marks = {}                                             # (index, lane) -> buckets
+        for (k, lane), i in last.items():
+            while i + 1 < len(self._bwd_recs) and self._bwd_recs[i + 1][0] == "wreduce" and lane_of(self._bwd_recs[i + 1]) == lane:
                 i += 1
-            last[k] = i
-        recs = []
+            marks.setdefault((i, lane), []).append(k)
+        recs, self.marks = [], []
         for i, r in enumerate(self._bwd_recs):
             recs.append(r)
-            for k, idx in sorted(last.items()):
+            for (idx, lane), ks in sorted(marks.items()):
                 if idx == i:
-                    recs.append(("event_record", L.EventArgs(events[k])))
-        ol = OpList.__new__(OpList)
-        OpList.__init__(ol, recs, lanes=True)
-        for j, r in enumerate(recs):                       # the record rides the lane of the reduction it follows
-            if r[0] == "event_record":
-                ol.arr[j].lane = ol.arr[j - 1].lane if j > 0 else 0
-        # buckets whose marks sit at the same point of the list complete together: the exchange may merge their collectives
+                    recs.append(("event_record", L.EventArgs(new_event(sorted(ks))), lane))
+                    self.marks.append((len(recs) - 1, lane, sorted(ks)))
+        ol = OpList(recs, lanes=True)
+        # buckets whose LAST marks sit at the same point of the list complete together: the exchange may merge their collectives
+        done_at = {}
+        for (idx, lane), ks in marks.items():
+            for k in ks:
+                done_at[k] = max(done_at.get(k, -1), idx)
         by_pos = {}
-        for k, idx in last.items():
+        for k, idx in done_at.items():
             by_pos.setdefault(idx, []).append(k)
         ol.coincident = [sorted(ks) for _, ks in sorted(by_pos.items())]
+        ol.marks = list(self.marks)
         return ol
 
     @staticmethod
@@ -186,7 +192,7 @@ class DeviceNet:
 
     @staticmethod
     def _group_reductions_lanes(plan, recs):
-        """Move every slab reduction to the end of its gradient bucket (ssdn.hip.dp.bucket_layers: head+dec1 | dec2..dec5 |
+        """Move every slab reduction to the end of its reduction run (ssdn.hip.dp.bucket_layers(split_head=False): head+dec1 | dec2..dec5 |
         encoder): the executor merges a run of consecutive SSDN_OP_WREDUCE ops into two launches, instead of two launches per
         layer (51 latency-bound launches, 0.52 ms per step in situ).  Legal: every weight-gradient launch owns its slab and
         the flat gradient is only read after the backward list.  Returns (records, layer name of each record if it is a
@@ -194,7 +200,7 @@ class DeviceNet:
         from .dp import bucket_layers
         if not plan.bwd:
             return recs, [op.a.get("layer") if op.type == "wreduce" else None for op in plan.bwd]
-        buckets = bucket_layers(plan.layers)
+        buckets = bucket_layers(plan.layers, split_head=False)
         bucket_of = {name: k for k, b in enumerate(buckets) for name in b}
         # The weight-gradient GEMMs of the layers at 16x16 pixels and below are issued together, where the last of them
         # stood: the executor runs a run of consecutive small SSDN_OP_WGRAD ops as ONE launch (k_wgrad_multi; same rule as
@@ -599,16 +605,23 @@ class DenoiserEngine:
             return
         self._tail_pending = False
         if exchange is not None and exchange.overlapped:
-            from .dp import bucket_layers
+            from .dp import bucket_layers, N_MAIN_BUCKETS as NB
             if getattr(self, "_bwd_ev_key", None) != id(exchange):
-                self._bwd_ev = self.main.bwd_with_events(bucket_layers(self.main.plan.layers), exchange.event_handles()[:3])
+                exchange.reset_marks()
+                self._bwd_ev = self.main.bwd_with_events(bucket_layers(self.main.plan.layers), exchange.new_event)
                 self._bwd_ev_key = id(exchange)
-                exchange.groups = [list(g) for g in self._bwd_ev.coincident] + [[k] for k in range(3, len(exchange.ranges))]
+                if len(exchange.ranges) > NB:
+                    exchange.record_here(NB)           # (creates the sigma bucket's mark; re-recorded behind its backward list below)
+                # the marks belong to THIS engine's list (an exchange may serve several engines, one per input shape)
+                self._bwd_ev_marks = (exchange.events, exchange.waits, exchange._here)
+                self._bwd_ev_groups = [list(g) for g in self._bwd_ev.coincident] + [[k] for k in range(NB, len(exchange.ranges))]
+            exchange.events, exchange.waits, exchange._here = self._bwd_ev_marks
+            exchange.groups = self._bwd_ev_groups
             self._bwd_ev.run(s)
             if self.sigma is not None:
                 self.sigma.bwd.run(s)
-            if len(exchange.ranges) > 3:
-                exchange.record_here(3)
+            if len(exchange.ranges) > NB:
+                exchange.record_here(NB)
             return
         self.main.bwd.run(s)
         if self.sigma is not None:

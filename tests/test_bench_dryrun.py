@@ -34,6 +34,9 @@ def test_bench_gpus2_self_spawns_and_prints_one_line():
     assert r["config"]["global_batch"] == 64 and r["config"]["parallelism"] == "dp2"
     assert abs(r["value"] - 3 * 64 / (r["ms_per_step"] * 3 / 1e3)) < 1e-2 * r["value"]
     assert "resident" not in r["data"]
+    # N > 1: the line says how long the optimiser waited for the gradient exchange behind the backward pass
+    assert r["allreduce_exposed_us"] is not None and r["allreduce_exposed_us"] >= 0 and r["allreduce"]["steps"] == 20
+    assert sum(r["allreduce"]["collectives_per_step_bytes"]) == 4 * 1269129
 
 
 def test_bench_single_rank_stub_line():

@@ -65,7 +65,7 @@ def _worker(rank, world, port, out):
     assert (r, w) == (rank, world)
     eng = StubEngine(rank, world)
     ex = dp.GradExchange(world, dp.bucket_ranges(LAYERS, NPAR, NPAR + 1), torch.device("cpu"))
-    assert not ex.overlapped and len(ex.ranges) == 4
+    assert not ex.overlapped and len(ex.ranges) == 5
     # the step driver of Denoiser.train_step / bench.py
     scale = dp.exchange_step(lambda e: eng.backward(exchange=e), eng.flat_grad, ex)
     assert eng.seen_exchange is ex and ex.pending == []
@@ -132,28 +132,29 @@ def test_bucket_ranges_cover_flat_buffer_in_backward_order():
     L = net_layers(3, 9, True)
     n = net_param_count(L)
     r = dp.bucket_ranges(L, n, n + 1)
-    assert r[0][1] == n and r[-1] == (n, n + 1) and r[2][0] == 0
+    assert r[0][1] == n and r[-1] == (n, n + 1) and r[3][0] == 0
     covered = sorted(r)
     assert covered[0][0] == 0 and all(covered[i][1] == covered[i + 1][0] for i in range(len(covered) - 1))
 
 
 def test_gradient_buckets_of_the_benchmark_network():
-    """the flat gradient of the blind-spot RGB network (BASELINE configs 2 / 3) is exchanged in <= 4 contiguous
-    buckets, in the order the backward pass completes them -- head + decode_block_1 | decode_block_2..5 | encoder | sigma
-    estimator -- which tile the whole buffer exactly once; sizes 1.42 / 3.15 / 0.50 / 4.41 MB."""
+    """the flat gradient of the blind-spot RGB network (BASELINE configs 2 / 3) is exchanged in <= 5 contiguous
+    buckets -- head | decode_block_1 | decode_block_2..5 | encoder | sigma estimator -- which tile the whole buffer exactly once;
+    sizes 0.74 / 0.67 / 3.15 / 0.50 / 4.41 MB."""
     layers = net_layers(3, 9, True)
     n_main = net_param_count(layers)
     n_sig = net_param_count(net_layers(3, 1, False))
     assert (n_main, n_sig) == (1269129, 1102177)
     r = dp.bucket_ranges(layers, n_main, n_main + n_sig)
-    assert r == [(914784, 1269129), (126048, 914784), (0, 126048), (1269129, 2371306)]
+    assert r == [(1083456, 1269129), (914784, 1083456), (126048, 914784), (0, 126048), (1269129, 2371306)]
     assert sorted(r)[0][0] == 0 and all(a[1] == b[0] for a, b in zip(sorted(r), sorted(r)[1:])) and sorted(r)[-1][1] == n_main + n_sig
-    assert [round((hi - lo) * 4 / 1e6, 2) for lo, hi in r] == [1.42, 3.15, 0.50, 4.41]
-    assert len(dp.bucket_ranges(layers, n_main, n_main)) == 3            # no sigma estimator: three buckets
+    assert [round((hi - lo) * 4 / 1e6, 2) for lo, hi in r] == [0.74, 0.67, 3.15, 0.50, 4.41]
+    assert len(dp.bucket_ranges(layers, n_main, n_main)) == dp.N_MAIN_BUCKETS == 4      # no sigma estimator: four buckets
     names = dp.bucket_layers(layers)
-    assert {"output_block.0", "output_block.2", "output_block.4", "decode_block_1.0", "decode_block_1.2"} == names[0]
-    assert all(n.startswith("decode_block_") for n in names[1]) and len(names[1]) == 8
-    assert all(n.startswith("encode_block_") for n in names[2]) and len(names[2]) == 7
+    assert {"output_block.0", "output_block.2", "output_block.4"} == names[0] and {"decode_block_1.0", "decode_block_1.2"} == names[1]
+    assert all(n.startswith("decode_block_") for n in names[2]) and len(names[2]) == 8
+    assert all(n.startswith("encode_block_") for n in names[3]) and len(names[3]) == 7
+    assert dp.bucket_layers(layers, split_head=False) == [names[0] | names[1], names[2], names[3]]
     off = {l.name: l.w_off for l in layers}
     for k, b in enumerate(names):                                          # a bucket's layers are exactly its range of the buffer
         assert all(r[k][0] <= off[n] < r[k][1] for n in b)
@@ -175,9 +176,35 @@ def test_coincident_buckets_are_exchanged_as_one_collective():
     plan = NetPlan("m/", 3, 9, True, 32, 64, 64, cus=256)
     flat = torch.zeros(plan.nparams)
     dn = DeviceNet(plan, torch.device("cpu"), flat, torch.zeros_like(flat))
-    ol = dn.bwd_with_events(dp.bucket_layers(plan.layers), [11, 22, 33])
+    handed = []
+
+    def new_event(ks):
+        handed.append(list(ks))
+        return 1000 + len(handed)
+    ol = dn.bwd_with_events(dp.bucket_layers(plan.layers), new_event)
     types = [int(ol.arr[i].type) for i in range(ol.n)]
+    lanes = [int(ol.arr[i].lane) for i in range(ol.n)]
     ev, red = L.OP["event_record"], L.OP["wreduce"]
-    assert types[-3:] == [ev, ev, ev] and types[-4] == red and ol.coincident == [[0, 1, 2]]
+    # plan "split": the side-lane launch (head layers + decode_block_2.2) reduces on lane 1 in the middle of the backward pass -- the head
+    # bucket (0) is complete THERE and is exchanged on its own, early; decode_block_2.2's bucket (2) has reductions on both lanes and
+    # gets a mark on each; the three buckets that end in the final run are coincident
+    assert handed == [[0, 2], [1, 2, 3]]
+    marks = [(i, lanes[i]) for i, t in enumerate(types) if t == ev]
+    assert [l for _, l in marks] == [1, 0] and marks[1][0] == ol.n - 1
+    assert types[marks[0][0] - 1] == red and lanes[marks[0][0] - 1] == 1 and types[-2] == red and lanes[-2] == 0
+    assert ol.coincident == [[0], [1, 2, 3]]
     runs = sum(1 for i, t in enumerate(types) if t == red and (i == 0 or types[i - 1] != red))
     assert runs == 2, "reductions: the side group's run and the final run, not split by the marks"
+    # every reduction of a bucket is followed, ON ITS OWN LANE, by a mark of that bucket (the collective must be
+    # ordered after every lane that wrote the bucket's range; lanes are only joined at the end of the list)
+    buckets = dp.bucket_layers(plan.layers)
+    for i, name in enumerate(dn._bwd_layers):
+        if name is None:
+            continue
+        k = next(j for j, b in enumerate(buckets) if name in b)
+        lane = dn._bwd_recs[i][2] if len(dn._bwd_recs[i]) > 2 else 1
+        assert any(ml == lane and k in ks and dn._bwd_recs.index(dn._bwd_recs[i]) < pos for pos, ml, ks in ol.marks), (name, lane)
+    # the exchange waits for ALL marks of the buckets of a unit
+    ex = dp.GradExchange(2, dp.bucket_ranges(plan.layers, plan.nparams, plan.nparams), torch.device("cpu"))
+    ex.groups = [list(g) for g in ol.coincident]
+    assert [(lo, hi, ks) for lo, hi, ks in ex._units()] == [(1083456, 1269129, [0]), (0, 1083456, [3, 2, 1])]

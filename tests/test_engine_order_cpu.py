@@ -69,3 +69,42 @@ def test_backward_list_order_invariants(cin, cout, bs, B, P):
         ks = [pos[i] for i in tail]
         between = [k for k in range(ks[0], ks[-1] + 1) if k not in ks]
         assert all(main_lane(k) for k in between), "side-lane records inside the chained run"
+
+
+@pytest.mark.parametrize("cin,cout,bs,B,P", [(3, 9, True, 32, 64), (3, 3, False, 4, 64), (1, 2, True, 2, 32), (3, 9, True, 16, 128)])
+def test_bucket_marks_cover_every_lane_that_reduced_the_bucket(cin, cout, bs, B, P):
+    """ADVICE round 4 (data-parallel race): the collective of a gradient bucket reads the bucket's range of the flat gradient, which slab
+    reductions on SEVERAL lanes may have written (plan "split": decode_block_2.2's on the side lane, the rest of its bucket on the main
+    lane) -- and the executor orders no lane after another before the end-of-list join.  So every reduction of a bucket must be followed,
+    on its OWN lane, by an SSDN_OP_EVENT_RECORD the bucket's collective waits for."""
+    import torch
+    from ssdn.hip import lib as L
+    plan = NetPlan("m/", cin, cout, bs, B, P, P, cus=256)
+    flat = torch.zeros(plan.nparams)
+    dn = E.DeviceNet(plan, torch.device("cpu"), flat, torch.zeros_like(flat))
+    buckets = bucket_layers(plan.layers)
+    waits = {}
+
+    def new_event(ks):
+        h = 7000 + len(waits)
+        waits[h] = list(ks)
+        return h
+    ol = dn.bwd_with_events(buckets, new_event)
+    ev = L.OP["event_record"]
+    recs = [(int(ol.arr[i].type), int(ol.arr[i].lane)) for i in range(ol.n)]
+    mark_at = {pos: (lane, ks) for pos, lane, ks in ol.marks}
+    assert all(recs[pos] == (ev, lane) for pos, (lane, _) in mark_at.items()) and sum(1 for t, _ in recs if t == ev) == len(mark_at)
+    # walk the emitted list: reductions in order of dn._bwd_recs, marks interleaved
+    j = -1
+    for pos, (t, lane) in enumerate(recs):
+        if t == ev:
+            continue
+        j += 1
+        name = dn._bwd_layers[j]
+        if name is None:
+            continue
+        k = next(i for i, b in enumerate(buckets) if name in b)
+        assert any(p > pos and ml == lane and k in ks for p, (ml, ks) in mark_at.items()), \
+            "reduction of %s (bucket %d, lane %d) has no later mark of its bucket on its lane" % (name, k, lane)
+    # every bucket with parameters is complete somewhere
+    assert sorted(k for ks in ol.coincident for k in ks) == [k for k, b in enumerate(buckets) if b]

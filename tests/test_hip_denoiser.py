@@ -257,7 +257,7 @@ def test_backward_with_bucket_events_is_bit_identical():
     d.flat_grad.fill_(float("nan"))
     net = d.get_model(Denoiser.MODEL, False)
     ex = dp.GradExchange(1, dp.bucket_ranges(net.layers, d._n_main, d.flat.numel()), d.device, force_events=True)
-    assert ex.overlapped and len(ex.ranges) == 4
+    assert ex.overlapped and len(ex.ranges) == 5
     d._run([noisy, ref, meta], clone=False)
     scale = dp.exchange_step(lambda e: eng.backward(exchange=e), d.flat_grad, ex)
     torch.cuda.synchronize()

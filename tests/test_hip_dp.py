@@ -169,7 +169,7 @@ def _rccl_world1(port, q):
         d = _make()
         ex = d.gradient_exchange(1)
         assert not ex.overlapped                       # world 1 without the switch: nothing to exchange
-        ex = dp.GradExchange(1, ex.ranges, d.device, force_events=True)
+        ex = dp.GradExchange(1, ex.ranges, d.device, force_events=True, timing_marks=True)
         assert ex.overlapped and ex.comm_stream is not None
         seen = []
         orig = dist.all_reduce
@@ -182,12 +182,16 @@ def _rccl_world1(port, q):
             got = _steps(d, noisy, clean, ex, nsteps=3)
         finally:
             dist.all_reduce = orig
+        torch.cuda.synchronize()
+        # when did the buckets complete?  (marks carry timestamps in this test): the head bucket's only mark vs the final one
+        early = 1e3 * ex.events[ex.waits[0][0]].elapsed_time(ex.events[ex.waits[1][-1]])
+        info = {"groups": ex.groups, "waits": {k: list(v) for k, v in ex.waits.items()}, "head_mark_to_final_mark_us": early}
         dist.destroy_process_group()
         # (buckets whose completion marks coincide -- all of the main net's with the chip-wide weight-gradient launch -- are ONE collective)
-        q.put(("ok", plain, got, seen, ex.comm_stream.cuda_stream, [hi - lo for lo, hi, _ in ex._units()]))
+        q.put(("ok", plain, got, seen, ex.comm_stream.cuda_stream, [hi - lo for lo, hi, _ in ex._units()], info))
     except Exception as e:      # noqa: BLE001
         import traceback
-        q.put(("err", traceback.format_exc(), None, None, None, None))
+        q.put(("err", traceback.format_exc(), None, None, None, None, None))
 
 
 def test_rccl_exchange_world_one_is_bit_identical():
@@ -199,10 +203,18 @@ def test_rccl_exchange_world_one_is_bit_identical():
     q = ctx.Queue()
     p = ctx.Process(target=_rccl_world1, args=(_free_port(), q))
     p.start()
-    tag, plain, got, seen, comm, sizes = q.get(timeout=600)
+    tag, plain, got, seen, comm, sizes, info = q.get(timeout=600)
     p.join(timeout=120)
     assert tag == "ok", plain
     assert np.array_equal(plain, got)
     # one asynchronous collective per (merged) bucket and step, issued from the communication stream
     assert len(seen) == 3 * len(sizes) and all(a for _, a, _ in seen) and all(s == comm for _, _, s in seen)
     assert sorted(n for n, _, _ in seen[:len(sizes)]) == sorted(sizes)
+    # plan "split" -- the head bucket (output_block.*: the side-lane launch's layers) is its own collective,
+    # issued FIRST and waiting only for the side lane's mark, which fires while the backward pass still has its bottom of the U and the
+    # chip-wide weight-gradient launch (~0.3 ms) in front of it; everything else is one collective behind the final reductions that
+    # waits for BOTH lanes' marks (decode_block_2.2's reduction ran on the side lane)
+    assert info["groups"] == [[0], [1, 2, 3]] and sizes == [1269129 - 1083456, 1083456]
+    assert [n for n, _, _ in seen[:2]] == sizes
+    assert len(info["waits"][0]) == 1 and len(info["waits"][2]) == 2 and info["waits"][0][0] in info["waits"][2]
+    assert info["head_mark_to_final_mark_us"] > 80.0, info      # (batch 4 here; ~0.4 ms at the benchmark batch)
