@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libssdn_hip.so")
+# SSDN_HIP_LIB: another build of the SAME library (tools/build_tuning.sh: -DSSDN_TUNING with ablation bits and stamps); never a fallback
+LIB_PATH = os.environ.get("SSDN_HIP_LIB") or os.path.join(_HERE, "libssdn_hip.so")
 MAX_TAPS = 9
 
 # op type codes (enum ssdn_op_type)

@@ -214,7 +214,8 @@ def test_rccl_exchange_world_one_is_bit_identical():
     # issued FIRST and waiting only for the side lane's mark, which fires while the backward pass still has its bottom of the U and the
     # chip-wide weight-gradient launch (~0.3 ms) in front of it; everything else is one collective behind the final reductions that
     # waits for BOTH lanes' marks (decode_block_2.2's reduction ran on the side lane)
-    assert info["groups"] == [[0], [1, 2, 3]] and sizes == [1269129 - 1083456, 1083456]
-    assert [n for n, _, _ in seen[:2]] == sizes
+    # (bucket 4: the 3 padding floats behind the main net's parameters / the learnable-sigma slot of the flat buffer)
+    assert info["groups"][:2] == [[0], [1, 2, 3]] and sizes[:2] == [1269129 - 1083456, 1083456], (info, sizes)
+    assert [n for n, _, _ in seen[:2]] == sizes[:2]
     assert len(info["waits"][0]) == 1 and len(info["waits"][2]) == 2 and info["waits"][0][0] in info["waits"][2]
     assert info["head_mark_to_final_mark_us"] > 80.0, info      # (batch 4 here; ~0.4 ms at the benchmark batch)
