@@ -19,17 +19,24 @@
 //     brute force over the ds_read_b128 lane groups: every fragment read is bank-conflict free.
 //   * Tile fetches are row items: one halo row = two 54-lane DMA instructions whose per-lane offsets never change.
 //   * Fragment addresses are one VGPR base + compile-time immediates (the 9 steps of a chunk are unrolled): per step a wave
-//     issues 15 ds_read_b128, a few DMA instructions and 18 MFMAs -- about one non-MFMA instruction per MFMA (k_conv: 17).
-//   * Epilogue: a wave owns 4 tile rows; it converts its accumulators, widens the 8-byte MFMA fragments to 16-byte pieces with
-//     v_permlane32_swap, transposes them through a wave-private LDS region (conflict-free ds_write_b128) and stores whole
-//     pixel-contiguous 1 KiB runs; mask / skip-gradient operands of the data-gradient role are fetched as one batch per pass.
-//     The other workgroup of the CU keeps the matrix cores busy meanwhile.
+//     issues 18 MFMAs, 15 ds_read_b128, a few DMA instructions and their scalar bookkeeping: ~85 instructions beside the MFMAs
+//     (k_conv: ~300).  Over a whole launch the SQ counters say 8.4 non-MFMA instructions per MFMA in round 4 (profiles/r04_pmc_cdma_fwd.txt:
+//     4.8 VALU + 2.7 SALU + 0.9 LDS), of which the epilogue and the per-tile head are more than half; round 5's direct epilogue
+//     halves the epilogue's share (profiles/r05_pmc_cdma_fwd.txt).
+//   * Epilogue (round 5, every variant but the fused UPSUM_BWD): a wave owns 4 tile rows; it converts its accumulators, widens the
+//     8-byte MFMA fragments to 16-byte pieces with v_permlane32_swap and stores each piece straight from registers (one per-lane
+//     offset + an immediate per piece + a scalar base per pass; LeakyReLU sign bytes from the lane's own eight channels); the fused
+//     UPSUM_BWD still transposes through a wave-private LDS region, because its 2x2 sums cross pixels.  mask / skip-gradient
+//     operands of the data-gradient role are fetched as one batch per pass.  The other workgroup of the CU keeps the matrix cores
+//     busy meanwhile -- when it is not in its own epilogue: the two workgroups of a CU start together and stay in phase
+//     (profiles/r05_k_cpipe_experiment.txt).
 //   * bias enters as the initial value of the accumulators.
 //
 // Shape class: 9 taps forming a 3x3 window (blind-spot, plain, or either one mirrored = data gradient), H and W multiples of
 // 16, 16-bit NHWC output, input channels = n chunks of 48 (+ one optional 16-channel tail chunk), each chunk from one source.
 #include "common.h"
 #include <cstdlib>
+#include <type_traits>
 
 // Tuning aids (ablation bits, phase stamps, weight replication) are compiled in only with -DSSDN_TUNING (`make TUNING=1`; tools/cdma_probe.sh
 // and the trace mode of tools/conv_bench.py need such a build): as run-time flags they cost ~40 scalar instructions and 10 branches PER STEP of a kernel that is
@@ -54,17 +61,18 @@ struct CdAux {
     int nitems, xcd_map;
     int nfull, tail16;          // 48-channel chunks, then an optional 16-channel chunk
     int ablate;                 // tuning aid (env SSDN_CDMA_ABLATE, read once): 1 no MFMA, 2 no weight DMA, 4 no tile DMA, 8 no epilogue,
-                                // 16 no DMA waits, 32 no step barriers, 64 DMA fetches nothing (zeros), 128 DMA with
-                                // all lanes masked (16..128: wrong results, timing only)
+                                // 16 no DMA waits, 32 no step barriers (16, 32: wrong results, timing only)
     int wrep;                   // experiment (env SSDN_CDMA_WREP): the weight tensor exists in `wrep` consecutive copies
     unsigned long long* trace;  // tuning aid (ssdn_debug_set_trace): s_memtime stamps, 32 per workgroup
 };
 
-__device__ __forceinline__ void dma16(unsigned lds_addr, int voff, u32x4_t rs, int soff) {
-    // M0 = LDS byte address of lane 0's 16 bytes; lane i lands at +16 i; EXEC-masked lanes write nothing, out-of-range lanes
-    // write zeros (tools/probes/probe_ldsdma.hip).  (s_nop: SGPR operands may be fresh from a VALU readfirstlane, and
-    // M0 -> LDS-DMA needs a wait state; nothing inside an asm statement is padded by the compiler)
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+// LDS-DMA through the compiler's builtin (round 5): it sets M0 and pads the SGPR hazards itself, only where needed.  As inline asm every
+// piece carried an `s_nop 4` (nothing inside an asm statement is padded by the compiler, and an SGPR operand may be fresh from a
+// v_readlane), which costs an MFMA-issuing wave 12-18 ns per piece (tools/probes/probe_dmacost.hip, profiles/r05_k_cpipe_experiment.txt).
+// lds_addr: wave-uniform LDS address of lane 0's 16 bytes; lane i lands at +16 i; EXEC-masked lanes write nothing, out-of-range lanes zeros
+typedef __attribute__((address_space(3))) void* cd_lds_ptr;
+__device__ __forceinline__ void dma16(unsigned lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cd_lds_ptr)(size_t)__builtin_amdgcn_readfirstlane(lds_addr), 16, voff, __builtin_amdgcn_readfirstlane(soff), 0, 0);
 }
 
 template <bool BF>
@@ -179,12 +187,10 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // ---- buffer resources ---------------------------------------------------------------------------------------------------
     // (num_records = 2 GiB for every resource: all tensors are smaller -- checked by the launcher -- and the one out-of-range
     //  offset used, 0x80000000, still reads as zero; constants cost no live SGPRs)
-    const unsigned long long wcp = (unsigned long long)a.wc;
-    const u32x4_t rs_wc = {(unsigned)wcp, (unsigned)(wcp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wc), 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
-    const unsigned long long p0 = (unsigned long long)a.src0.p, p1 = (unsigned long long)a.src1.p;
-    const u32x4_t rs_s0 = {(unsigned)p0, (unsigned)(p0 >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
-    const u32x4_t rs_s1 = {(unsigned)p1, (unsigned)(p1 >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const __amdgpu_buffer_rsrc_t rs_s0 = __builtin_amdgcn_make_buffer_rsrc(a.src0.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(a.src1.p ? a.src1.p : a.src0.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const int nch = x.nfull + x.tail16;
 
     int tr_i = 0;
@@ -236,25 +242,22 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     };
     // everything about the rows of one (tile, chunk) that does not depend on the row: prepared ONCE per chunk, on the scalar unit
     // (plain scalars, not a struct: in some instantiations a struct of them was placed in scratch)
-    auto row_ctx = [&](const CdTile& t, int c, int tpar, u32x4_t& o_rs, int& o_rbase, int& o_rstride, int& o_ybs, int& o_ush, unsigned& o_dst) __attribute__((always_inline)) {
+    auto row_ctx = [&](const CdTile& t, int c, int tpar, bool& o_rs, int& o_rbase, int& o_rstride, int& o_ybs, int& o_ush, unsigned& o_dst) __attribute__((always_inline)) {
         const int k0 = c * 48;
         const bool from0 = k0 < a.c0;
         const bool up = from0 && a.up0;
-        const u32x4_t rs = from0 ? rs_s0 : rs_s1;
         const int cs = from0 ? a.src0.cs : a.src1.cs;
         const int cbase = from0 ? a.src0.co + k0 : a.src1.co + k0 - a.c0;
         const int Hs = up ? H0 : a.H, Ws = up ? W0 : a.W;
-        // (readfirstlane: the values ARE wave-uniform; saying so once per chunk keeps the nine steps' row arithmetic on the
-        //  scalar unit -- the asm "s" operands of dma16 are not something the compiler would otherwise guarantee)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o_rs[q] = __builtin_amdgcn_readfirstlane(rs[q]);
+        // (readfirstlane: the values ARE wave-uniform; saying so once per chunk keeps the nine steps' row arithmetic on the scalar unit)
+        o_rs = from0;
         o_rstride = __builtin_amdgcn_readfirstlane(Ws * cs * 2);
         o_rbase = __builtin_amdgcn_readfirstlane((t.n * Hs * Ws * cs + cbase) * 2);
         o_ybs = __builtin_amdgcn_readfirstlane(t.y0 - x.padT);
         o_ush = up ? 1 : 0;
         o_dst = __builtin_amdgcn_readfirstlane(tlds0 + tpar * CD_TBYTES);
     };
-    auto issue_rows = [&](u32x4_t rc_rs, int rc_rbase, int rc_rstride, int rc_ybs, int rc_ush, unsigned rc_dst, bool full, int rlE, int rlO, int u0, int nu) __attribute__((always_inline)) {
+    auto issue_rows = [&](bool rc_from0, int rc_rbase, int rc_rstride, int rc_ybs, int rc_ush, unsigned rc_dst, bool full, int rlE, int rlO, int u0, int nu) __attribute__((always_inline)) {
         if (CD_ABL(x, 4)) return;
         const bool act = full ? lane < 54 : lane < 36;
 #pragma unroll
@@ -268,8 +271,9 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             const int soff = rc_rbase + (y >> rc_ush) * rc_rstride;            // (an out-of-image row fetches nothing: voff is out of range)
             const int voff = rowok ? ((hy & 1) ? rlO : rlE) : (int)0x80000000;
             const unsigned ldsrow = rc_dst + hy * (full ? 1728 : 576) + half * 864;
-            if (CD_ABL(x, 128)) { if (lane > 64) dma16(ldsrow, voff, rc_rs, soff); }
-            else if (act) dma16(ldsrow, CD_ABL(x, 64) ? (int)0x80000000 : voff, rc_rs, soff);
+            if (act) {
+                if (rc_from0) dma16(ldsrow, voff, rs_s0, soff); else dma16(ldsrow, voff, rs_s1, soff);
+            }
         }
     };
 
@@ -291,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     if (tid < WROWS) bl[tid] = (a.bias && tid < x.m_cnt) ? a.bias[x.m_base + tid] : 0.f;
     if (wload) issue_w(wchunk(0), 0 < x.nfull, 0, 0);
     else {
-        u32x4_t q_rs; int q_rbase, q_rstride, q_ybs, q_ush; unsigned q_dst;
+        bool q_rs; int q_rbase, q_rstride, q_ybs, q_ush; unsigned q_dst;
         row_ctx(cur, 0, 0, q_rs, q_rbase, q_rstride, q_ybs, q_ush, q_dst);
         issue_rows(q_rs, q_rbase, q_rstride, q_ybs, q_ush, q_dst, 0 < x.nfull, row_lane(cur, 0, 0), row_lane(cur, 0, 1), 0, 18);
     }
@@ -342,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             const bool pf_full = pc < x.nfull;
             int rlE = 0, rlO = 0;
             if (!wload && pf) { rlE = row_lane(pt, pc, 0); rlO = row_lane(pt, pc, 1); }
-            u32x4_t rc_rs; int rc_rbase, rc_rstride, rc_ybs, rc_ush; unsigned rc_dst;      // (unconditional: scalar values defined on one
+            bool rc_rs; int rc_rbase, rc_rstride, rc_ybs, rc_ush; unsigned rc_dst;      // (unconditional: scalar values defined on one
             row_ctx(pt, pc, tpar ^ 1, rc_rs, rc_rbase, rc_rstride, rc_ybs, rc_ush, rc_dst);  //  path only end up in VGPRs)
             const int wcb_c = wchunk(c), wcb_p = wchunk(pc);
             const bool cfull = c < x.nfull;
@@ -411,7 +415,130 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             stamp();
         }
 
-        // ---- epilogue: the tile buffer of the last chunk (tpar ^ 1 now) is dead; the other one holds / receives the next tile ----
+        // ---- epilogue, direct form (round 5; every variant but the fused UPSUM_BWD, whose 2x2 sums need the transposed tile): after the
+        // permlane swap lane (pixel l31, kh) holds the whole 16-byte piece mt*4 + 2gp + kh of its pixel -- it stores it straight from
+        // registers (32-byte runs at a 192-byte pitch; the L2 merges the four pieces of a 64-byte sector, they arrive within a few hundred
+        // cycles) and, for the LeakyReLU sign bytes, works on its own eight channels.  ONE per-lane offset per tensor + an immediate per
+        // (mt, gp) + the pass's scalar base as soffset: no LDS round trip (24 LDS ops, their waits), no per-piece address arithmetic
+        // (~170 VALU per wave and tile), sign byte in 13 instead of ~28 instructions: ~890 -> ~450 instructions per wave and tile in the
+        // forward role, ~990 -> ~530 in the data-gradient role (no LeakyReLU there: compile-time), measured in tools/ab_libs.sh.
+        if (!CD_ABL(x, 8) && !HAS_UPS && (cpp & 1) == 0) {
+            const int pix_t = (cur.n * a.H + cur.y0 + 4 * w) * a.W + cur.x0;     // first pixel of this wave's 4 rows
+            const int lrow = l31 >> 4, lcol = l31 & 15;
+            const int lpix = lrow * a.W + lcol;
+            int ur_base = 0, ur_iu = 0, ur_iv = 0, ur_ju = 0, ur_jv = 0;
+            if constexpr (UROT) {
+                const int Bq = a.N >> 2, P1 = a.H - 1;
+                const int r = (cur.n >= Bq ? 1 : 0) + (cur.n >= 2 * Bq ? 1 : 0) + (cur.n >= 3 * Bq ? 1 : 0);
+                ur_iu = r == 0 ? 1 : (r == 2 ? -1 : 0); ur_iv = r == 1 ? 1 : (r == 3 ? -1 : 0);
+                ur_ju = r == 3 ? 1 : (r == 1 ? -1 : 0); ur_jv = r == 0 ? 1 : (r == 2 ? -1 : 0);
+                const int i0 = r >= 2 ? P1 : 0, j0 = (r == 1 || r == 2) ? P1 : 0;
+                ur_base = (((cur.n - r * Bq) * a.H + i0) * a.W + j0) * a.urot.cs + a.urot.co + r * a.M;
+            }
+            auto pass = [&](auto NtC, auto ActC) __attribute__((always_inline)) {
+                constexpr int nt = decltype(NtC)::value;
+                constexpr bool ACTC = decltype(ActC)::value != 0;
+                const int pix_p = pix_t + 2 * nt * a.W;
+                // per-lane offsets of piece kh of this lane's pixel (pieces mt*4 + 2gp + kh: + an immediate), scalar bases as soffset
+                int d_lane, d_so = 0;
+                bool live = true;
+                if constexpr (UROT) {
+                    const int u = cur.y0 + 4 * w + 2 * nt + lrow + 1, v = cur.x0 + lcol;
+                    live = u < a.H;                                   // row P-1 falls off the shifted image
+                    const int dpx = (ur_iu * u + ur_iv * v) * a.W + ur_ju * u + ur_jv * v;
+                    d_lane = live ? (ur_base + dpx * a.urot.cs + x.m_base) * 2 + kh * 16 : (int)0x80000000;
+                } else {
+                    d_lane = lpix * a.dst.cs * 2 + kh * 16;
+                    d_so = __builtin_amdgcn_readfirstlane((pix_p * a.dst.cs + a.dst.co + x.m_base) * 2);
+                }
+                const int s_lane = live ? lpix * (a.M >> 3) + kh : (int)0x80000000;       // sign bytes: M / 8 bytes per pixel
+                const int s_so = __builtin_amdgcn_readfirstlane(pix_p * (a.M >> 3) + (x.m_base >> 3));
+                // operands of the data-gradient role: one batch of loads per pass, in flight while the accumulators are converted
+                u32x4_t ab[MT * 2], mb[MT * 2];
+#pragma unroll
+                for (int i = 0; i < MT * 2; ++i) {
+                    if (i * 2 >= cpp) break;
+                    if constexpr (HAS_ADD)
+                        ab[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, lpix * a.add.cs * 2 + kh * 16 + i * 32,
+                                                                      __builtin_amdgcn_readfirstlane((pix_p * a.add.cs + a.add.co + x.m_base) * 2), 0);
+                    if constexpr (HAS_MASK && SMASK)
+                        mb[i][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_ms, s_lane + i * 2, s_so, 0);
+                    else if constexpr (HAS_MASK)
+                        mb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, lpix * a.mask.cs * 2 + kh * 16 + i * 32,
+                                                                      __builtin_amdgcn_readfirstlane((pix_p * a.mask.cs + a.mask.co + x.m_base) * 2), 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int gp = 0; gp < 2; ++gp) {
+                        constexpr int DUMMY = 0; (void)DUMMY;
+                        const int i = mt * 2 + gp;
+                        if (i * 2 >= cpp) break;                  // (cpp is even here: the pieces 2i, 2i+1 exist together)
+                        unsigned pk[2][2];
+#pragma unroll
+                        for (int h = 0; h < 2; ++h) {
+                            float v[4];
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                v[j] = acc[mt][nt][(2 * gp + h) * 4 + j];
+                                if constexpr (ACTC) v[j] = fmaxf(v[j], LRELU_SLOPE * v[j]);
+                            }
+                            pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
+                            pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
+                        }
+                        u32x4_t o;
+#pragma unroll
+                        for (int d = 0; d < 2; ++d) {
+                            auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
+                            o[d] = r[0]; o[2 + d] = r[1];
+                        }
+                        if constexpr (HAS_MASK || HAS_ADD) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                float v0, v1;
+                                if constexpr (BF) {
+                                    v0 = bf_lo(o[q]); v1 = bf_hi(o[q]);
+                                    if constexpr (HAS_ADD) { v0 += bf_lo(ab[i][q]); v1 += bf_hi(ab[i][q]); }
+                                } else {
+                                    v0 = f16_lo(o[q]); v1 = f16_hi(o[q]);
+                                    if constexpr (HAS_ADD) { v0 += f16_lo(ab[i][q]); v1 += f16_hi(ab[i][q]); }
+                                }
+                                if constexpr (HAS_MASK) {
+                                    int mlo, mhi;
+                                    if constexpr (SMASK) { mlo = (mb[i][0] >> (2 * q)) & 1u; mhi = (mb[i][0] >> (2 * q + 1)) & 1u; }
+                                    else { mlo = (int)(short)(mb[i][q] & 0xffffu); mhi = (int)mb[i][q] >> 16; }
+                                    v0 *= mlo > 0 ? 1.f : LRELU_SLOPE;
+                                    v1 *= mhi > 0 ? 1.f : LRELU_SLOPE;
+                                }
+                                o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
+                            }
+                        }
+                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, d_lane + i * 32, d_so, 0);
+                        if constexpr (UROT || SOUT) {
+                            if (SOUT || a.urot_smask) {
+                                // sign byte of the piece: bit 2q = (low half of dword q > 0), bit 2q+1 = (high half > 0), on the raw 16-bit
+                                // patterns: min(max(h, 0), 1) per half, then the eight 0/1 halves are merged by shifts
+                                // (asm: written with __builtin_elementwise_max / _min on short2 the compiler folded the four dwords into one)
+                                unsigned rq[4];
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    unsigned t0;
+                                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(t0) : "v"(o[q]));
+                                    asm("v_pk_min_i16 %0, %1, %2" : "=v"(rq[q]) : "v"(t0), "s"(0x00010001u));
+                                }
+                                const unsigned t01 = (rq[1] << 2) | rq[0], t23 = (rq[3] << 2) | rq[2];
+                                const unsigned t = (t23 << 4) | t01;              // bits 0,2,4,6: low halves; 16,18,20,22: high halves
+                                const unsigned sb = t | (t >> 15);
+                                __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_sgn, s_lane + i * 2, s_so, 0);
+                            }
+                        }
+                    }
+            };
+            if (a.act) { pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 1>{}); pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 1>{}); }
+            else { pass(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}); pass(std::integral_constant<int, 1>{}, std::integral_constant<int, 0>{}); }
+        } else
+        // ---- epilogue through LDS (fused UPSUM_BWD; blocks with an odd number of 8-channel pieces): the tile buffer of the last chunk
+        // (tpar ^ 1 now) is dead; the other one holds / receives the next tile ----
         if (!CD_ABL(x, 8)) {
             char* reg = tbuf0 + (tpar ^ 1) * CD_TBYTES + w * (32 * OSTR);
             const int pix_t = (cur.n * a.H + cur.y0 + 4 * w) * a.W + cur.x0;     // first pixel of this wave's 4 rows
