@@ -1,6 +1,6 @@
 """TEST INFRASTRUCTURE -- full-size parity fixtures from the LIVE reference (build container only: needs /root/reference).
 
-    python oracle/gen_golden_fullsize.py          -> tests/golden/g_full_cfg2.npz, g_full_cfg5.npz   (a few KB each)
+    python oracle/gen_golden_fullsize.py [tag ...] -> tests/golden/g_full_cfg2|cfg3|cfg4|cfg5|cfg5b.npz   (a few KB each)
 
 The small fixtures of oracle/gen_golden.py are all batch 2, <= 64x64.  These two drive the reference's own Denoiser
 (run_pipeline + torch.mean(LOSS).backward(), train.py:200-201) at the sizes the bench and the config-5 shard run: batch 32 at
@@ -43,14 +43,23 @@ def main():
             ssdn.cfg.infer(cfg, model_only=True)
             d = Denoiser(cfg, device="cpu")
             d._models[Denoiser.MODEL].load_state_dict(R.reference_state_dict(F.params(tag)))
+            if F.sigma_params(tag) is not None:
+                d._models[Denoiser.SIGMA_ESTIMATOR].load_state_dict(R.reference_state_dict(F.sigma_params(tag)))
             clean, noisy, npar = F.inputs(tag)
             meta = {MD.INPUT_NOISE_VALUES: npar, MD.IMAGE_SHAPE: None, MD.CLEAN: clean}
-            o = d.run_pipeline([noisy, clean, meta])
+            refimg = clean
+            if alg == "n2v":
+                refimg, coords = F.n2v_extras(tag)
+                meta[MD.MASK_COORDS] = coords
+            o = d.run_pipeline([noisy, refimg, meta])
             torch.mean(o[PipelineOutput.LOSS]).backward()
             arrs = {"names": np.array([n for n, _ in d.named_parameters()]), "loss": o[PipelineOutput.LOSS].detach().numpy(),
                     "out_probe": o[PipelineOutput.IMG_DENOISED].detach()[:, :, 3::16, 5::16].numpy(),
-                    "mu_probe": o[PipelineOutput.IMG_MU].detach()[:, :, 3::16, 5::16].numpy(),
                     "psnr_out": np.array([float(ssdn.utils.calculate_psnr(o[PipelineOutput.IMG_DENOISED].detach()[b:b + 1], clean[b:b + 1])) for b in range(B)])}
+            if PipelineOutput.IMG_MU in o:
+                arrs["mu_probe"] = o[PipelineOutput.IMG_MU].detach()[:, :, 3::16, 5::16].numpy()
+            if PipelineOutput.NOISE_STD_DEV in o:
+                arrs["noise_std"] = o[PipelineOutput.NOISE_STD_DEV].detach().reshape(B, -1)[:, :4].numpy()
             for n, prm in d.named_parameters():
                 f = prm.grad.reshape(-1)
                 arrs["gnorm/" + n] = np.float64(f.double().norm())

@@ -206,29 +206,34 @@ def test_param_grads(golden_dir, tag, alg, style, mode, ch):
         close(t.grad.reshape(-1)[:16], g["ghead/" + name], rtol=5e-3, atol=1e-6 + 1e-4 * gn)
 
 
-@pytest.mark.parametrize("tag", ["cfg2", "cfg5", "cfg5b"])
+@pytest.mark.parametrize("tag", ["cfg2", "cfg3", "cfg4", "cfg5", "cfg5b"])
 def test_full_size_oracle_vs_reference(golden_dir, tag):
-    """The restatement at the sizes the bench and the config-5 shard RUN (batch 32 at 64x64; batch 16 at 128x128) against what the
-    live reference produced there (oracle/gen_golden_fullsize.py): per-sample loss, per-tensor gradient norm and first entries,
-    probes of the posterior mean and of mu, per-image PSNR."""
+    """The restatement at the sizes the bench and the per-rank shards of configs 3, 4 and 5 RUN (batch 32 at 64x64; batch 16 at 128x128)
+    against what the live reference produced there (oracle/gen_golden_fullsize.py): per-sample loss, per-tensor gradient norm and first
+    entries (for config 3 also the sigma-estimation network's), probes of the output image (and of mu), per-image PSNR."""
     import fullsize as F
     g = G(golden_dir, "g_full_" + tag)
     alg, style, mode, B, P = F.CASES[tag]
-    tr = R.CpuTrainer(alg, 3, style, mode, params=F.params(tag))
+    tr = R.CpuTrainer(alg, 3, style, mode, params=F.params(tag), sigma_params=F.sigma_params(tag))
     clean, noisy, npar = F.inputs(tag)
+    ref, coords = (F.n2v_extras(tag) if alg == "n2v" else (clean, None))
     torch.set_num_threads(min(8, os.cpu_count() or 1))
-    r = tr.forward(noisy, clean, npar)
+    r = tr.forward(noisy, ref, npar, coords)
     r["loss"].mean().backward()
     close(r["loss"], g["loss"], rtol=2e-4, atol=1e-4)
     close(r["out"].detach()[:, :, 3::16, 5::16], g["out_probe"], rtol=1e-3, atol=5e-5)
-    close(r["out_mu"].detach()[:, :, 3::16, 5::16], g["mu_probe"], rtol=1e-3, atol=5e-5)
+    if "mu_probe" in g:
+        close(r["out_mu"].detach()[:, :, 3::16, 5::16], g["mu_probe"], rtol=1e-3, atol=5e-5)
     for b in range(B):
         assert float(R.psnr(r["out"].detach()[b:b + 1], clean[b:b + 1])) == pytest.approx(float(g["psnr_out"][b]), abs=2e-3)
+    nsig = 0
     for name, (net, key) in param_name_map(g["names"]).items():
-        t = tr.est if net == "est" else tr.p[key]
+        t = tr.est if net == "est" else (tr.ps if net == "sigma" else tr.p)[key]
+        nsig += net == "sigma"
         gn = float(t.grad.double().norm())
         assert gn == pytest.approx(float(g["gnorm/" + name]), rel=2e-3, abs=1e-7), name
         close(t.grad.reshape(-1)[:16], g["ghead/" + name], rtol=5e-3, atol=1e-6 + 2e-4 * gn)
+    assert nsig == (40 if tag == "cfg3" else 0)
 
 
 def test_checkpoint_contract(golden_dir):
