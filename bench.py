@@ -28,6 +28,7 @@ Prints ONE JSON line (rank 0) with `value` = whole-job patches/s of that loop, p
 import argparse
 import ctypes as C
 import json
+import re
 import os
 import sys
 import time
@@ -427,12 +428,24 @@ def run_rank(args):
         # HBM-side traffic of the same kernel family: PMC passes cannot run inside this process, so the per-launch figure is
         # the committed result of tools/pmc_traffic.sh (FETCH_SIZE x2 + WRITE_SIZE); null if absent
         traffic, traffic_src = None, None
-        for cand in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json"):      # the committed PMC summary of THIS kernel (tools/pmc_traffic.sh)
+        lib_sha = None
+        try:
+            import hashlib
+            with open(L.LIB_PATH, "rb") as f:
+                lib_sha = hashlib.sha256(f.read()).hexdigest()
+        except OSError:
+            pass
+        # the newest committed PMC summary of THIS kernel (tools/pmc_traffic.sh) -- quoted only if it was collected with the library this
+        # run loaded (lib_sha256 in the summary): a figure of another build says nothing about the benchmarked binary
+        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_traffic\.json$", f)), reverse=True):
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     tj = json.load(f)
+                if tj.get("lib_sha256") != lib_sha:
+                    traffic_src = "profiles/%s describes another build of the library (its lib_sha256 differs): not quoted" % cand
+                    break
                 traffic = int(tj["hbm_bytes_per_launch"])
-                traffic_src = "profiles/%s (collected at %s)" % (cand, tj.get("collected_at", "?"))
+                traffic_src = "profiles/%s (collected at %s, same library build: sha256 %s...)" % (cand, tj.get("collected_at", "?"), lib_sha[:12])
                 break
             except (OSError, KeyError, ValueError):
                 continue
