@@ -310,12 +310,13 @@ def run_rank(args):
         d.train_step(stream.prepare(cur, idx), lr_now(), exchange)
         seen += B * world
 
-    # (the collector is off inside the timed region, as in the standard library's timeit: a generation-2 pass of this process takes
-    #  longer than a training step, and the driver's 20-step region is 34 ms.  Collected BEFORE the warm-up steps, so that the device does
-    #  not sit idle -- and clock down -- between them and the timed region)
+    # (the collector: the policy of DenoiserTrainer.train() -- everything alive goes to the permanent generation before the first step, so the
+    #  automatic passes inside the timed region only see what the steps themselves allocate (a generation-2 pass over the whole heap takes
+    #  longer than a training step, and the driver's 20-step region is 34 ms).  Collected BEFORE the warm-up steps, so that the device does not
+    #  sit idle -- and clock down -- between them and the timed region)
     import gc
     gc.collect()
-    gc.disable()
+    gc.freeze()
     for i in range(args.warmup):
         step(i)
 
@@ -334,7 +335,6 @@ def run_rank(args):
         step(i)
     barrier()
     dt = time.perf_counter() - t0
-    gc.enable()
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

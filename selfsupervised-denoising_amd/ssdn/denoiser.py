@@ -313,6 +313,7 @@ class Denoiser(nn.Module):
 
     # ---- H11: per-step metrics on the device ---------------------------------------------------------------------------
     METRIC_NAMES = ("loss", "psnr_out", "psnr_mu_out", PipelineOutput.NOISE_STD_DEV.value, PipelineOutput.MODEL_STD_DEV.value)
+    assert len(METRIC_NAMES) <= 7       # the accumulator is 16 floats: (sum, count) per metric in [0, 14), the kernel's arrival counter in [15]
 
     def _metrics_acc(self, kind: str) -> Tensor:
         accs = self.__dict__.setdefault("_macc", {})
@@ -344,12 +345,19 @@ class Denoiser(nn.Module):
         eng.accumulate_metrics(self._metrics_acc(kind), clean, ext, with_loss=with_loss and self._has_loss_last)
         self._metrics_keep = (clean, ext)               # alive until the launch has run
         if per_sample:
-            per = eng.metrics_per.cpu()
+            per = eng.metrics_per.cpu()                      # (synchronises: the launch has run)
+            if kind != "train":
+                self._metrics_acc(kind).zero_()              # only the per-sample values of such a batch are used: its sums must not pile up
             res = {"psnr_out": per[:, 1].clone()}
             if self._pipeline == Pipeline.SSDN:
                 res["psnr_mu_out"] = per[:, 2].clone()
             return res
         return None
+
+    def reset_device_metrics(self, kind: str = "train"):
+        """forget what `accumulate_metrics` has summed on the device since the last read (the trainer's reset_metrics)"""
+        if kind in self.__dict__.get("_macc", {}):
+            self._macc[kind].zero_()
 
     def read_metrics(self, kind: str = "train", reset: bool = True) -> Dict[str, Tuple[float, int]]:
         """{metric name: (sum over samples, sample count)} accumulated since the last reset -- ONE 64-byte copy to the host."""

@@ -175,6 +175,13 @@ class DenoiserTrainer:
         train_history = history[HistoryValue.TRAIN]
         MD = NoisyDataset.Metadata
         data_itr = iter(self.trainloader)
+        # The collector and a 1.7 ms step: a generation-2 pass over this process's heap (torch, the planned engines, the dataset) takes longer
+        # than a training step.  Everything alive now goes to the permanent generation (gc.freeze), so the automatic passes inside the loop
+        # only see what the loop itself allocated; a full collection runs where the loop stops anyway, at PRINT_INTERVAL.  bench.py times
+        # its steps under the same policy.
+        import gc
+        gc.collect()
+        gc.freeze()
         while True:
             iteration = self.state[StateValue.ITERATION]
             if iteration % self.cfg[ConfigValue.EVAL_INTERVAL] == 0 and self.testloader is not None:
@@ -190,6 +197,7 @@ class DenoiserTrainer:
                     self.write_metrics(eval_prefix="valid")
                 last_print.total = 0
                 self.reset_metrics()
+                gc.collect()
             if iteration % self.cfg[ConfigValue.SNAPSHOT_INTERVAL] == 0 and self.rank == 0:
                 self.snapshot()
             if iteration >= self.cfg[ConfigValue.TRAIN_ITERATIONS]:
@@ -338,6 +346,8 @@ class DenoiserTrainer:
         return "{} | ".format(prefix) + ", ".join(self._metric_strs(self.state[StateValue.HISTORY][HistoryValue.EVAL]))
 
     def reset_metrics(self, eval: bool = True, train: bool = True):
+        if train and hasattr(getattr(self, "denoiser", None), "reset_device_metrics"):
+            self.denoiser.reset_device_metrics("train")     # (sums the steps since the last flush left on the device go with the host Metrics)
         hist = self.state[StateValue.HISTORY]
         for on, key in ((train, HistoryValue.TRAIN), (eval, HistoryValue.EVAL)):
             if on:
