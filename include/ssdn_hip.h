@@ -35,7 +35,7 @@ extern "C" {
 #pragma GCC visibility push(default)
 #endif
 
-#define SSDN_ABI_VERSION 13
+#define SSDN_ABI_VERSION 14
 #define SSDN_MAX_TAPS 9
 
 /* NHWC fp16 view: element (n,y,x,c) lives at p[((n*H + y)*W + x)*cs + co + c]. */
@@ -537,6 +537,38 @@ int ssdn_conv_set_chain(int on);
  * run is "mergeable": at most 32768 pixels (the layers at the bottom of the U), mblocks <= 1, and a tiling the merged kernel
  * carries an instance for.  The result is bit-identical to one launch per op.  Returns 1 if `a` is mergeable, else 0. */
 int ssdn_wgrad_mergeable(const ssdn_wgrad_args* a);
+
+/* ---- step-level entry points: a whole configuration through libssdn_hip.so alone ------------------------------------------------
+ * replaces: one iteration of the reference's training loop (ssdn/ssdn/train.py:196-202: run_pipeline -> mean(LOSS).backward() ->
+ * optimizer.step()) and Denoiser.forward (ssdn/ssdn/denoiser.py:112-126), for ONE configuration and input shape.
+ * A plan blob is written by the Python planner (DenoiserEngine.export_plan(), ssdn/hip/engine.py): the op lists of a step with every
+ * pointer replaced by (tensor, offset), the tensor table, and a JSON description (configuration, shapes, the parameter layout of the
+ * flat fp32 buffer: per layer name / w_off / b_off / M / cin / k, checkpoint order OIHW).  The library lays the tensors out in ONE
+ * caller-owned device arena; the caller fills the named input tensors and reads the named outputs:
+ *     "params" "grads" "adam_m" "adam_v"      flat fp32 buffers (a fresh arena must be ZERO: ssdn_plan_arena_bytes() bytes)
+ *     "m/in32"        fp32 [B,C,H,W] network input (noisy image)          "noise_param"  fp32 [B] (ssdn, sigma known: std dev / lambda)
+ *     "ref"           fp32 [B,C,H,W] reference image (mse / mask_mse)     "coords"       int64 [ncoords,2] (mask_mse)
+ *     "loss"          fp32 [B]      "pme" "mu" fp32 [B,C,H,W] (ssdn: posterior mean / mu)     "m/out32" fp32 net_out
+ * Phases: SSDN_PLAN_REPACK (fp16 / bf16 MFMA shadows from "params": after the caller has written parameters), SSDN_PLAN_FORWARD
+ * (network + loss head), SSDN_PLAN_BACKWARD (gradients into "grads"), SSDN_PLAN_OPTIMISER (fused Adam + re-pack).  Everything is
+ * enqueued asynchronously on `stream` (a hipStream_t; the library's side streams are ordered after it and joined into it).
+ * Not thread-safe per plan; one plan per process / GPU.  All functions return 0 or a negative status with ssdn_last_error(). */
+#define SSDN_PLAN_REPACK 0
+#define SSDN_PLAN_FORWARD 1
+#define SSDN_PLAN_BACKWARD 2
+#define SSDN_PLAN_OPTIMISER 3
+#define SSDN_PLAN_PHASES 4
+typedef struct ssdn_plan ssdn_plan;
+int ssdn_plan_load(const void* blob, int64_t nbytes, ssdn_plan** out);
+void ssdn_plan_destroy(ssdn_plan* plan);
+int64_t ssdn_plan_arena_bytes(const ssdn_plan* plan);      /* device bytes the caller provides (256-byte aligned, zero-filled) */
+const char* ssdn_plan_meta(const ssdn_plan* plan);         /* the blob's JSON description */
+int ssdn_plan_bind(ssdn_plan* plan, void* arena);
+int ssdn_plan_tensor(const ssdn_plan* plan, const char* name, void** ptr, int64_t* bytes);
+int ssdn_plan_run(ssdn_plan* plan, int phase, void* stream);
+int ssdn_plan_set_lr(ssdn_plan* plan, float lr, int step, float gscale);   /* Adam: learning rate, step count (1-based: bias corrections), gradient scale */
+int ssdn_net_forward(ssdn_plan* plan, void* stream);                       /* = phase SSDN_PLAN_FORWARD */
+int ssdn_train_step(ssdn_plan* plan, float lr, int step, void* stream);    /* forward + loss, backward, Adam(lr, step) + re-pack */
 
 /* Tuning aid (tools/conv_bench.py): device buffer that receives 32 s_memtime stamps per workgroup of the MFMA kernels, or
  * NULL (default) for none. */

@@ -573,6 +573,84 @@ class DenoiserEngine:
         a.ext = _ptr(ext) if ext is not None else None
         self._metrics_ops.run(current_stream() if stream is None else stream)
 
+    # ---- export: the whole step as a blob libssdn_hip.so runs on its own (csrc/plan.hip, include/ssdn_hip.h "step-level entry points") ----
+    def export_plan(self, meta: Optional[dict] = None) -> bytes:
+        """The op lists of this engine with every pointer replaced by (tensor, offset), the tensor table, and a JSON description.
+        ssdn_plan_load() + ssdn_plan_bind() rebuild them in one caller-owned arena; ssdn_train_step() / ssdn_net_forward() run them --
+        a binder needs the library and this blob, not the Python package."""
+        import json
+        import struct
+        tens: List[tuple] = []                       # (name, tensor)
+        for name, t in self.main.t.items():
+            tens.append((name, t))
+        if self.sigma is not None:
+            for name, t in self.sigma.t.items():
+                tens.append((name, t))
+        tens += [("params", self.params), ("grads", self.grads), ("adam_m", self.m), ("adam_v", self.v), ("loss", self.loss), ("ref", self.ref),
+                 ("noise_param", self.noise_param), ("coords", self.coords), ("partial", self.partial), ("est_raw", self.est_raw),
+                 ("g_est_var", self.g_est_var), ("mu", self.mu), ("pme", self.pme), ("model_std", self.model_std), ("noise_std", self.noise_std),
+                 ("zero_buf", self.zero_buf), ("metrics_per", self.metrics_per)]
+        tens = [(n, t) for n, t in tens if t is not None]
+        table, by_ptr = [], {}
+        for name, t in tens:
+            nbytes = t.numel() * t.element_size()
+            ptr = t.data_ptr()
+            alias = by_ptr.get(ptr, -1)
+            if alias >= 0 and table[alias][1] < nbytes:
+                raise L.SsdnHipError("export_plan: tensor %s aliases a smaller one" % name)
+            if alias < 0:
+                by_ptr[ptr] = len(table)
+            table.append((name, nbytes, alias, ptr))
+        spans = sorted((ptr, ptr + nb, i) for i, (n, nb, al, ptr) in enumerate(table) if al < 0)
+
+        def locate(v):
+            for lo, hi, i in spans:
+                if lo <= v < hi or (v == hi == lo):
+                    return i, v - lo
+            raise L.SsdnHipError("export_plan: an op argument points outside every tensor of the engine (0x%x)" % v)
+        ptr_off = {ty: L.pointer_fields(ty) for ty in set(L.ARG_TYPES.values())}
+
+        def ser(oplists):
+            out, n = b"", 0
+            for ol in oplists:
+                if ol is None:
+                    continue
+                for i in range(ol.n):
+                    a = ol.args[i]
+                    raw = bytes(a)
+                    rel = b""
+                    nr = 0
+                    for off in ptr_off[type(a)]:
+                        v = struct.unpack_from("<Q", raw, off)[0]
+                        if v:
+                            ti, d = locate(v)
+                            rel += struct.pack("<IIQ", off, ti, d)
+                            nr += 1
+                    pad = (-len(raw)) % 8
+                    out += struct.pack("<iiII", int(ol.arr[i].type), int(ol.arr[i].lane), len(raw), nr) + raw + b"\0" * pad + rel
+                    n += 1
+            return struct.pack("<I", n) + out
+        train = self.train
+        phases = [[self.main.pack, self.sigma.pack if self.sigma is not None else None],
+                  [self.main.fwd, self.sigma.fwd if self.sigma is not None else None, self.ops_loss],
+                  [self.main.bwd, self.sigma.bwd if self.sigma is not None else None] if train else [],
+                  [self.ops_opt] if train else []]
+        layers = lambda net, base: [dict(name=l.name, w_off=base + l.w_off, b_off=base + l.b_off, M=l.M, cin=l.cin, k=l.k) for l in net.plan.layers]   # noqa: E731
+        desc = dict(pipeline=self.pipeline, channels=self.C, blindspot=bool(self.blindspot), style=self.style, mode=self.mode, B=self.B, H=self.H,
+                    W=self.W, train=bool(train), nparams=int(self.params.numel()), est_off=self.est_off,
+                    layers=layers(self.main, 0) + (layers(self.sigma, self.sigma.plan.param_base) if self.sigma is not None else []))
+        desc.update(meta or {})
+        mj = json.dumps(desc).encode()
+        blob = b"SSDNPLAN" + struct.pack("<IIII", 1, L.ABI_VERSION, len(table), 4)
+        for name, nb, al, _ in table:
+            nm = name.encode()
+            if len(nm) > 55:
+                raise L.SsdnHipError("export_plan: tensor name too long: " + name)
+            blob += nm + b"\0" * (56 - len(nm)) + struct.pack("<Qii", nb, al, 0)
+        for ph in phases:
+            blob += ser(ph)
+        return blob + struct.pack("<I", len(mj)) + mj
+
     # ---- execution -----------------------------------------------------------------------------------------
     def repack(self, stream=None):
         s = current_stream() if stream is None else stream

@@ -129,14 +129,29 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
                  mse=MseArgs, mask_mse=MseArgs, adam=AdamArgs, metrics=MetricsArgs, zero=ZeroArgs, event_record=EventArgs, noise=NoiseArgs)
 
 # every symbol include/ssdn_hip.h declares
-ABI_VERSION = 13      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
+ABI_VERSION = 14      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
 SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
            "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_conv_fuses_urot", "ssdn_conv_signs", "ssdn_chain_len",
-           "ssdn_conv_set_chain", "ssdn_wgrad_mega_ok", "ssdn_wgrad_variant"]
+           "ssdn_conv_set_chain", "ssdn_wgrad_mega_ok", "ssdn_wgrad_variant",
+           "ssdn_plan_load", "ssdn_plan_destroy", "ssdn_plan_arena_bytes", "ssdn_plan_meta", "ssdn_plan_bind", "ssdn_plan_tensor", "ssdn_plan_run",
+           "ssdn_plan_set_lr", "ssdn_net_forward", "ssdn_train_step"]
+PLAN_PHASES = dict(repack=0, forward=1, backward=2, optimiser=3)
 PROF = dict(conv_mt3=0, conv_mt2=1, conv_mt1=2, wgrad=3, gemm=4, cdma_mt3=5, cdma_mt21=6, wgrad_side=7)
+
+def pointer_fields(st, base: int = 0):
+    """byte offsets of every pointer inside a (nested) argument struct: c_void_p fields and the `p` of ssdn_view"""
+    out = []
+    for name, ty in st._fields_:
+        off = base + getattr(st, name).offset
+        if ty is vp:
+            out.append(off)
+        elif isinstance(ty, type) and issubclass(ty, C.Structure):
+            out += pointer_fields(ty, off)
+    return out
+
 
 _lib = None
 
@@ -197,6 +212,26 @@ def load() -> C.CDLL:
     lib.ssdn_wgrad_variant.restype = C.c_int
     lib.ssdn_struct_size.argtypes = [C.c_int]
     lib.ssdn_struct_size.restype = C.c_int
+    lib.ssdn_plan_load.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_void_p)]
+    lib.ssdn_plan_load.restype = C.c_int
+    lib.ssdn_plan_destroy.argtypes = [C.c_void_p]
+    lib.ssdn_plan_destroy.restype = None
+    lib.ssdn_plan_arena_bytes.argtypes = [C.c_void_p]
+    lib.ssdn_plan_arena_bytes.restype = C.c_int64
+    lib.ssdn_plan_meta.argtypes = [C.c_void_p]
+    lib.ssdn_plan_meta.restype = C.c_char_p
+    lib.ssdn_plan_bind.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ssdn_plan_bind.restype = C.c_int
+    lib.ssdn_plan_tensor.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+    lib.ssdn_plan_tensor.restype = C.c_int
+    lib.ssdn_plan_run.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.ssdn_plan_run.restype = C.c_int
+    lib.ssdn_plan_set_lr.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_float]
+    lib.ssdn_plan_set_lr.restype = C.c_int
+    lib.ssdn_net_forward.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ssdn_net_forward.restype = C.c_int
+    lib.ssdn_train_step.argtypes = [C.c_void_p, C.c_float, C.c_int, C.c_void_p]
+    lib.ssdn_train_step.restype = C.c_int
     if lib.ssdn_abi_version() != ABI_VERSION:
         raise SsdnHipError("libssdn_hip.so ABI version mismatch")
     _lib = lib

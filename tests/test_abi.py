@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def test_library_loads_and_exports_header_symbols():
     lib = L.load()
     hdr = open(os.path.join(ROOT, "include", "ssdn_hip.h")).read()
-    declared = set(re.findall(r"^\s*(?:int|const char\*|void\*?)\s+(ssdn_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
+    declared = set(re.findall(r"^\s*(?:int|int64_t|const char\*|void\*?)\s+(ssdn_[a-z0-9_]+)\s*\(", hdr, flags=re.M))
     assert declared == set(L.SYMBOLS), (declared ^ set(L.SYMBOLS))
     for s in declared:
         assert hasattr(lib, s), s
@@ -67,3 +67,32 @@ def test_graft_entry_build_is_consistent():
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     g = importlib.import_module("__graft_entry__")
     g.build()
+
+
+def test_plan_blob_loader_on_the_host():
+    """The step-level entry points' loader (csrc/plan.hip) needs no GPU: a hand-made blob with two tensors (one an alias) and no ops loads,
+    reports its arena size and description, resolves names after a bind; a truncated blob, a foreign ABI number and an argument struct of
+    the wrong size are refused with a message."""
+    import struct
+    lib = L.load()
+
+    def blob(abi=L.ABI_VERSION, ops=b"", nops=0, cut=0):
+        t = b"".join(n.encode().ljust(56, b"\0") + struct.pack("<Qii", nb, al, 0) for n, nb, al in (("params", 1000, -1), ("m/in32", 4096, -1), ("inp", 4096, 1)))
+        meta = b'{"B": 2}'
+        b = b"SSDNPLAN" + struct.pack("<IIII", 1, abi, 3, 4) + t + struct.pack("<I", nops) + ops + struct.pack("<I", 0) * 3 + struct.pack("<I", len(meta)) + meta
+        return b[:len(b) - cut]
+    plan = C.c_void_p()
+    good = blob()
+    assert lib.ssdn_plan_load(good, len(good), C.byref(plan)) == 0, lib.ssdn_last_error()
+    assert lib.ssdn_plan_arena_bytes(plan) == 1024 + 4096 and lib.ssdn_plan_meta(plan) == b'{"B": 2}'
+    assert lib.ssdn_plan_run(plan, 1, None) != 0 and b"not bound" in lib.ssdn_last_error()
+    assert lib.ssdn_plan_bind(plan, C.c_void_p(0x10000)) == 0
+    p, n = C.c_void_p(), C.c_int64()
+    assert lib.ssdn_plan_tensor(plan, b"inp", C.byref(p), C.byref(n)) == 0 and p.value == 0x10000 + 1024 and n.value == 4096
+    assert lib.ssdn_plan_tensor(plan, b"nope", C.byref(p), C.byref(n)) != 0
+    assert lib.ssdn_plan_set_lr(plan, 3e-4, 1, 1.0) != 0            # (no optimiser in this plan)
+    lib.ssdn_plan_destroy(plan)
+    for bad, msg in ((blob(cut=5), b"truncated"), (blob(abi=L.ABI_VERSION + 1), b"ABI"),
+                     (blob(ops=struct.pack("<iiII", L.OP["adam"], 0, 8, 0) + b"\0" * 8, nops=1), b"argument bytes")):
+        plan = C.c_void_p()
+        assert lib.ssdn_plan_load(bad, len(bad), C.byref(plan)) != 0 and msg in lib.ssdn_last_error(), lib.ssdn_last_error()
