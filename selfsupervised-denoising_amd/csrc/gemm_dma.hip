@@ -30,8 +30,12 @@ struct GdAux {
     int M4, act4, HW;
 };
 
-__device__ __forceinline__ void gd_dma16(unsigned lds_addr, int voff, u32x4_t rs, int soff) {
-    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_addr), "v"(voff), "s"(rs), "s"(soff) : "memory");
+// LDS-DMA through the compiler's builtin (round 5): it sets M0 and pads SGPR hazards only where needed; as inline asm every piece carried
+// an `s_nop 4` (tools/probes/probe_dmacost.hip: 12-18 ns per piece for an MFMA-issuing wave; a loader wave here issues 4-6 pieces per chunk).
+// Exactly one VMEM instruction per call: the vmcnt group accounting below counts them.
+typedef __attribute__((address_space(3))) void* gd_lds_ptr;
+__device__ __forceinline__ void gd_dma16(unsigned lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (gd_lds_ptr)(size_t)__builtin_amdgcn_readfirstlane(lds_addr), 16, voff, __builtin_amdgcn_readfirstlane(soff), 0, 0);
 }
 
 template <bool BF>
@@ -86,9 +90,8 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     const int ntl = (x.ntiles - (int)blockIdx.x + G - 1) / G;        // tiles of this workgroup
     const int total = ntl * x.nch;                                   // its chunk stream
 
-    const unsigned long long ap = (unsigned long long)a.src0.p, wgp = (unsigned long long)a.w;
-    const u32x4_t rs_a = {(unsigned)ap, (unsigned)(ap >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
-    const u32x4_t rs_w = {(unsigned)wgp, (unsigned)(wgp >> 32) & 0xffffu, 0x80000000u, SSDN_BUFFER_RSRC_FLAGS};
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(a.src0.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
