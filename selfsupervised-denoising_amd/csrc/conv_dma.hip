@@ -61,7 +61,8 @@ struct CdAux {
     int nitems, xcd_map;
     int nfull, tail16;          // 48-channel chunks, then an optional 16-channel chunk
     int ablate;                 // tuning aid (env SSDN_CDMA_ABLATE, read once): 1 no MFMA, 2 no weight DMA, 4 no tile DMA, 8 no epilogue,
-                                // 16 no DMA waits, 32 no step barriers (16, 32: wrong results, timing only)
+                                // 16 no DMA waits, 32 no step barriers (16, 32: wrong results, timing only), 64 epilogue stores dropped by a
+                                // zero-size buffer resource (the arithmetic and the issue slots stay)
     int wrep;                   // experiment (env SSDN_CDMA_WREP): the weight tensor exists in `wrep` consecutive copies
     unsigned long long* trace;  // tuning aid (ssdn_debug_set_trace): s_memtime stamps, 32 per workgroup
 };
@@ -302,8 +303,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
-    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(UROT ? a.urot.p : a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_sgn = __builtin_amdgcn_make_buffer_rsrc(SOUT ? a.sign_out : a.urot_smask, 0, (SOUT || (UROT && a.urot_smask)) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(UROT ? a.urot.p : a.dst.p, 0, CD_ABL(x, 64) ? 0 : (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_sgn = __builtin_amdgcn_make_buffer_rsrc(SOUT ? a.sign_out : a.urot_smask, 0, (!CD_ABL(x, 64) && (SOUT || (UROT && a.urot_smask))) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_ms = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(HAS_UPS ? a.upsum_mask_sign : a.mask_sign), 0, SMASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const float slope = a.act ? LRELU_SLOPE : 1.f;
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, HAS_MASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
