@@ -28,7 +28,14 @@ struct GdAux {
     const float* b4;    // or NULL
     float* out32;
     int M4, act4, HW;
+    int ablate;   // tuning aid (env SSDN_GDMA_ABLATE, `make TUNING=1` builds only): 1 no epilogue, 2 the epilogue's stores are dropped by a zero-size
+                  // buffer resource, 8 the epilogue stops behind the registers -> LDS half
 };
+#ifdef SSDN_TUNING
+#define GD_ABL(xx, bit) (((xx).ablate & (bit)) != 0)
+#else
+#define GD_ABL(xx, bit) false
+#endif
 
 // LDS-DMA through the compiler's builtin (round 5): it sets M0 and pads SGPR hazards only where needed; as inline asm every piece carried
 // an `s_nop 4` (tools/probes/probe_dmacost.hip: 12-18 ns per piece for an MFMA-issuing wave; a loader wave here issues 4-6 pieces per chunk).
@@ -46,7 +53,12 @@ __device__ __forceinline__ f32x16 gd_mma(half8 av, half8 bv, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
 }
 
-constexpr int GD_DA = 3, GD_DB = 3;
+#ifndef GD_DA_V
+#define GD_DA_V 3
+#define GD_DB_V 3
+#endif
+constexpr int GD_DA = GD_DA_V, GD_DB = GD_DB_V;
+constexpr int GD_LUT_BYTES = 256;       // 16 x float4 behind the scratch KiB: sign nibble -> LeakyReLU' factors
 constexpr int gd_eg(int wm) { return wm == 6 ? 2 : wm; }       // channel tiles per epilogue transpose group
 
 // wait until all but the newest n groups of PER DMA instructions of this wave have landed
@@ -80,6 +92,7 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     constexpr int EG = gd_eg(WM), NEG = WM / EG;             // epilogue: channel tiles per transpose group
     constexpr int OSTR = EG * 64 + 16, NEK = EG * 2, CPP = EG * 4;
     constexpr int BOFF = DA * ABYTES, EOFF = BOFF + DB * BBYTES, BIAS_OFF = EOFF + NW * 32 * OSTR, DUMMY_OFF = BIAS_OFF + TM * 4;
+    constexpr int LUT_OFF = DUMMY_OFF + 1024;                // 16 x float4: the LeakyReLU' factors of a sign nibble (GD_LUT_BYTES)
     constexpr bool HAS_MASK = (EPI & 1) != 0, UNROT = (EPI & 2) != 0, OUT4 = (EPI & 4) != 0, SMASK = (EPI & 8) != 0, SOUT = (EPI & 16) != 0;
     static_assert(!OUT4 || (NWM == 1 && WM == 3 && gd_eg(WM) == 3 && !BF), "the fused narrow layer needs the wave's whole 96-channel tile in its LDS region");
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
@@ -92,12 +105,12 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
 
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(a.src0.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, GD_ABL(x, 2) ? 0 : (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT && !GD_ABL(x, 2) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_um = __builtin_amdgcn_make_buffer_rsrc(a.unrot_mask.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_us = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(UNROT ? a.unrot_smask : a.mask_sign), 0, SMASK ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_so = __builtin_amdgcn_make_buffer_rsrc(a.sign_out, 0, SOUT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+    const __amdgpu_buffer_rsrc_t rs_so = __builtin_amdgcn_make_buffer_rsrc(a.sign_out, 0, SOUT && !GD_ABL(x, 2) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
 
     // DMA lane constants: lane -> (row lane >> 2 of a 16-row instruction, LDS piece lane & 3); the piece fetched is the swizzled one
     const int drow = lane >> 2, dpiece = (lane & 3) ^ ((drow >> 2) & 3);
@@ -142,6 +155,11 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     for (int c = 0; c < lead && c < total; ++c) issue_next();
     float* bl = reinterpret_cast<float*>(smem + BIAS_OFF);
     if (tid < TM) bl[tid] = (a.bias && tid < a.M) ? a.bias[tid] : 0.f;
+    if constexpr (SMASK) {
+        // LeakyReLU' of four channels from their four sign bits: entry n = {bit j of n ? 1 : slope}, one ds_read_b128 per nibble instead of
+        // a bit test, a select and a scalar multiply per channel (the epilogue is VALU-bound: profiles/r05_gdma_epilogue.txt)
+        if (tid < 64) reinterpret_cast<float*>(smem + LUT_OFF)[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 1.f : LRELU_SLOPE;
+    }
     half8 w4f[6];                         // OUT4: the narrow layer's weights, rows l31, K = 96 in six K-steps: registers for the whole launch
     if constexpr (OUT4) {
 #pragma unroll
@@ -197,6 +215,7 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
             ++done;
         }
         // ---- epilogue of the tile (wave-private; the rings keep filling meanwhile) ----
+        if (GD_ABL(x, 1)) continue;
 #pragma unroll
         for (int pt = 0; pt < WP; ++pt) {
             const int pix_p = pix0 + (wp * WP + pt) * 32;
@@ -213,9 +232,14 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                         for (int h = 0; h < 2; ++h) {
                             float v[4];
 #pragma unroll
-                            for (int q = 0; q < 4; ++q) {
-                                v[q] = acc[mt][pt][(2 * gp + h) * 4 + q];
-                                v[q] = fmaxf(v[q], slope * v[q]);
+                            for (int q = 0; q < 4; ++q) v[q] = acc[mt][pt][(2 * gp + h) * 4 + q];
+                            if constexpr (!BF) {      // LeakyReLU (slope 1: identity); the data-gradient role (bf16) has none -- gemm_dma_eligible
+#pragma unroll
+                                for (int q = 0; q < 4; q += 2) {
+                                    const f32x2_t t = f32x2_t{v[q], v[q + 1]} * slope;          // v_pk_mul_f32
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[q]) : "v"(v[q]), "v"(t[0]));           // (fmaxf: + a canonicalising v_max per value)
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[q + 1]) : "v"(v[q + 1]), "v"(t[1]));
+                                }
                             }
                             pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
                             pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
@@ -252,10 +276,30 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                         x.out32[((long long)n4 * x.M4 + m) * x.HW + rem] = v;
                     }
                 }
+                if (GD_ABL(x, 8)) continue;      // tuning: conversion + LDS writes only
                 // LDS -> HBM: 32 pixels x CPP 16-byte pieces, pixel-contiguous runs of EG * 64 bytes
                 u32x4_t mb[NEK];
                 int goff[NEK], loff[NEK];
                 bool live[NEK];
+                // fused un-rotation: the destination pixel of (b, iy, jx) in rotation r's tensor is AFFINE in (iy, jx) --
+                //   r=0: (u, v) = (iy, jx)   r=1: (P-1-jx, iy)   r=2: (P-1-iy, P-1-jx)   r=3: (jx, P-1-iy);   row u-1 (u == 0: the shift cut the
+                //   pixel off, zeros go to row P-1 = "row -1 + P") -- so a piece costs two multiply-adds on coefficients picked ONCE per group
+                //   from the lane's channel block instead of two four-way selects per piece (round 5: the epilogue is VALU-bound)
+                [[maybe_unused]] int ur_cI = 0, ur_cJ = 0, ur_c0 = 0, ur_uI = 0, ur_uJ = 0, ur_u0 = 0, ur_cc = 0;
+                if constexpr (UNROT) {
+                    static_assert(!UNROT || CPP == 8, "lane -> (pixel lane >> 3, piece lane & 7)");
+                    int ln = lane;
+                    asm volatile("" : "+v"(ln));          // opaque: per-group values are recomputed here, not hoisted over the K loop (192 accumulators live)
+                    const int P = 1 << x.lp, ch = chb + ((ln & 7) << 3);
+                    const int r = (ch >= 96 ? 1 : 0) + (ch >= 192 ? 1 : 0) + (ch >= 288 ? 1 : 0);
+                    ur_cc = ch - r * 96;
+                    ur_cI = r == 0 ? P : (r == 1 ? 1 : (r == 2 ? -P : -1));
+                    ur_cJ = r == 0 ? 1 : (r == 1 ? -P : (r == 2 ? -1 : P));
+                    ur_c0 = (r == 0 ? -P : (r == 1 ? (P - 2) * P : (r == 2 ? (P - 2) * P + P - 1 : -1))) + ((r * a.N) << (2 * x.lp));
+                    ur_uI = r == 0 ? 1 : (r == 2 ? -1 : 0);
+                    ur_uJ = r == 3 ? 1 : (r == 1 ? -1 : 0);
+                    ur_u0 = (r == 1 || r == 2) ? P - 1 : 0;
+                }
 #pragma unroll
                 for (int k = 0; k < NEK; ++k) {
                     const int p = k * 64 + lane;
@@ -264,20 +308,16 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                     loff[k] = px * OSTR + c16;
                     live[k] = true;
                     if constexpr (UNROT) {
-                        // (b, i, j) of the pixel (H == W == P, a power of two), rotation r of the piece's 96-channel block
                         const int lp = x.lp, P = 1 << lp;
                         const int jx = pix & (P - 1), iy = (pix >> lp) & (P - 1), b = pix >> (2 * lp);
-                        const int ch = chb + (c16 >> 1);
-                        const int r = ch >= 288 ? 3 : (ch >= 192 ? 2 : (ch >= 96 ? 1 : 0)), cc = ch - r * 96;
-                        const int u = r == 0 ? iy : (r == 1 ? P - 1 - jx : (r == 2 ? P - 1 - iy : jx));
-                        const int v = r == 0 ? jx : (r == 1 ? iy : (r == 2 ? P - 1 - jx : P - 1 - iy));
-                        live[k] = u >= 1;                                  // u == 0: the shift cut it off -> zero row y = P-1
-                        const int dpix = (((((r * a.N + b) << lp) + (u >= 1 ? u - 1 : P - 1))) << lp) + v;
-                        goff[k] = (dpix * a.unrot.cs + a.unrot.co + cc) * 2;
+                        const int u = __mul24(ur_uI, iy) + __mul24(ur_uJ, jx) + ur_u0;
+                        live[k] = u >= 1;
+                        const int dpix = __mul24(ur_cI, iy) + __mul24(ur_cJ, jx) + ur_c0 + (b << (2 * lp)) + (live[k] ? 0 : P << lp);
+                        goff[k] = (int)__umul24(dpix, a.unrot.cs * 2) + (a.unrot.co + ur_cc) * 2;      // (dpix < 2^24: gemm_dma_eligible bounds 4 N H W cs)
                         if constexpr (SMASK)      // one sign byte per 16-byte piece (written by SSDN_OP_UNROT_FWD), 12 bytes per pixel
-                            mb[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_us, live[k] ? dpix * 12 + (cc >> 3) : (int)0x80000000, 0, 0);
+                            mb[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_us, live[k] ? (int)__umul24(dpix, 12) + (ur_cc >> 3) : (int)0x80000000, 0, 0);
                         else
-                            mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (dpix * a.unrot_mask.cs + a.unrot_mask.co + cc) * 2 : (int)0x80000000, 0, 0);
+                            mb[k] = __builtin_amdgcn_raw_buffer_load_b128(rs_um, live[k] ? (int)__umul24(dpix, a.unrot_mask.cs * 2) + (a.unrot_mask.co + ur_cc) * 2 : (int)0x80000000, 0, 0);
                     } else {
                         goff[k] = (pix * a.dst.cs + a.dst.co + chb) * 2 + c16;
                         if constexpr (HAS_MASK && SMASK) mb[k][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_us, pix * (a.M >> 3) + (chb >> 3) + (c16 >> 4), 0, 0);
@@ -290,7 +330,18 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                     if constexpr (UNROT) {
                         if (!live[k]) o = u32x4_t{0u, 0u, 0u, 0u};
                     }
-                    if constexpr (HAS_MASK || UNROT) {
+                    if constexpr ((HAS_MASK || UNROT) && SMASK && BF) {
+                        // sign byte: bit 2q = low half of dword q, bit 2q+1 = its high half -> nibble 0 = dwords 0-1, nibble 1 = dwords 2-3
+                        const unsigned sb = mb[k][0];
+                        const f32x4 m0 = *reinterpret_cast<const f32x4*>(smem + LUT_OFF + ((sb & 15u) << 4));
+                        const f32x4 m1 = *reinterpret_cast<const f32x4*>(smem + LUT_OFF + ((sb >> 4) << 4));      // (a zero-extended byte)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const f32x2_t v = f32x2_t{bf_lo(o[q]), bf_hi(o[q])} *
+                                              (q < 2 ? f32x2_t{m0[2 * q], m0[2 * q + 1]} : f32x2_t{m1[2 * q - 4], m1[2 * q - 3]});
+                            o[q] = pack_bf16x2(v[0], v[1]);
+                        }
+                    } else if constexpr (HAS_MASK || UNROT) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             float v0, v1;
@@ -306,11 +357,19 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
                     }
                     if constexpr (UNROT) __builtin_amdgcn_raw_buffer_store_b128(o, rs_ur, goff[k], 0, 0);
                     else __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, goff[k], 0, 0);
-                    if constexpr (SOUT) {      // sign byte of the piece: bit q = (channel q > 0), on the raw fp16 halves
-                        unsigned sb = 0;
+                    if constexpr (SOUT) {
+                        // sign byte of the piece: bit 2q = (low half of dword q > 0), bit 2q+1 = (high half > 0), on the raw 16-bit patterns:
+                        // min(max(h, 0), 1) per half, then the eight 0/1 halves merged by shifts (k_cdma's form: 13 instructions, not ~21)
+                        unsigned rq[4];
 #pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            sb |= ((int)(short)(o[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q) | (((int)o[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                        for (int q = 0; q < 4; ++q) {
+                            unsigned t0;
+                            asm("v_pk_max_i16 %0, %1, 0" : "=v"(t0) : "v"(o[q]));
+                            asm("v_pk_min_i16 %0, %1, %2" : "=v"(rq[q]) : "v"(t0), "s"(0x00010001u));
+                        }
+                        const unsigned t01 = (rq[1] << 2) | rq[0], t23 = (rq[3] << 2) | rq[2];
+                        const unsigned t = (t23 << 4) | t01;              // bits 0,2,4,6: low halves; 16,18,20,22: high halves
+                        const unsigned sb = t | (t >> 15);
                         const int p = k * 64 + lane, px = p / CPP, c16 = (p - px * CPP) << 4;
                         __builtin_amdgcn_raw_buffer_store_b8((unsigned char)sb, rs_so, (pix_p + px) * (a.M >> 3) + (chb >> 3) + (c16 >> 4), 0, 0);
                     }
@@ -331,6 +390,7 @@ bool gemm_dma_eligible(const ssdn_conv_args* a) {
     const long long px = (long long)a->N * a->H * a->W;
     if (px % 256) return false;
     if (!a->bf16 && a->mask.p) return false;
+    if (a->bf16 && a->act) return false;      // the data-gradient role's epilogue has no LeakyReLU (compile-time)
     int csmax = a->dst.cs > a->src0.cs ? a->dst.cs : a->src0.cs;
     csmax = csmax > a->mask.cs ? csmax : a->mask.cs;
     if (px * csmax * 2 >= (1ll << 31)) return false;
@@ -349,13 +409,13 @@ bool gemm_dma_signs(const ssdn_conv_args* a) {
 
 int gemm_dma_lds_bytes(const ssdn_conv_args* a) {
     const int tm = a->Mpad == 384 ? 384 : 96, eg = a->Mpad == 384 ? 2 : 3;
-    return GD_DA * 256 * 64 + GD_DB * tm * 64 + 8 * 32 * (eg * 64 + 16) + tm * 4 + 1024;
+    return GD_DA * 256 * 64 + GD_DB * tm * 64 + 8 * 32 * (eg * 64 + 16) + tm * 4 + 1024 + GD_LUT_BYTES;
 }
 
 template <int WP, int WM, int NWP, int NWM, bool BF, int EPI>
 static int gd_launch(const ssdn_conv_args* a, hipStream_t s, const ssdn_conv_args* a4 = nullptr) {
     constexpr int TP = NWP * WP * 32, TM = NWM * WM * 32;
-    constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + NWP * NWM * 32 * (gd_eg(WM) * 64 + 16) + TM * 4 + 1024;
+    constexpr int LDS = GD_DA * TP * 64 + GD_DB * TM * 64 + NWP * NWM * 32 * (gd_eg(WM) * 64 + 16) + TM * 4 + 1024 + GD_LUT_BYTES;
     static_assert(TP == 256 && NWP * NWM == 8, "gemm_dma_lds_bytes assumes 256-pixel tiles and 8 waves");
     static_assert(LDS <= 160 * 1024, "LDS");
     static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
@@ -371,6 +431,8 @@ static int gd_launch(const ssdn_conv_args* a, hipStream_t s, const ssdn_conv_arg
     const double px = (double)a->N * a->H * a->W;
     x.ntiles = (int)(px / TP);
     x.w4 = nullptr; x.b4 = nullptr; x.out32 = nullptr; x.M4 = 0; x.act4 = 0; x.HW = a->H * a->W;
+    static const int env_ablate = [] { const char* e = ssdn_tuning_env("SSDN_GDMA_ABLATE"); return e ? atoi(e) : 0; }();
+    x.ablate = env_ablate;
     if (a4) { x.w4 = (const h16*)a4->w; x.b4 = a4->bias; x.out32 = a4->dst32; x.M4 = a4->M; x.act4 = a4->act; }
     const int kreal = a->kreal > 0 ? a->kreal : a->Ktot;
     prof_begin(SSDN_PROF_GEMM, s);
