@@ -294,6 +294,13 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // instruction that would land there are EXEC-masked)
     float* const bl = reinterpret_cast<float*>(smem + 18 * 18 * 96);
     if (tid < WROWS) bl[tid] = (a.bias && tid < x.m_cnt) ? a.bias[x.m_base + tid] : 0.f;
+    // ... and, behind the bias (96 floats at most), 16 x float4: the LeakyReLU' factors of four channels from their four sign bits (entry n =
+    // {bit j of n ? 1 : slope}): one ds_read_b128 per nibble instead of a bit test, a select and a scalar multiply per channel
+    constexpr int CD_LUT = 18 * 18 * 96 + 384;
+    static_assert(CD_LUT + 256 <= CD_TBYTES && WROWS * 4 <= 384, "pad behind tile buffer 0");
+    if constexpr (SMASK && HAS_MASK) {
+        if (tid < 64) reinterpret_cast<float*>(smem + CD_LUT)[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 1.f : LRELU_SLOPE;
+    }
     if (wload) issue_w(wchunk(0), 0 < x.nfull, 0, 0);
     else {
         bool q_rs; int q_rbase, q_rstride, q_ybs, q_ush; unsigned q_dst;
@@ -480,9 +487,14 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         for (int h = 0; h < 2; ++h) {
                             float v[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                v[j] = acc[mt][nt][(2 * gp + h) * 4 + j];
-                                if constexpr (ACTC) v[j] = fmaxf(v[j], LRELU_SLOPE * v[j]);
+                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][(2 * gp + h) * 4 + j];
+                            if constexpr (ACTC) {      // LeakyReLU = max(v, slope v): v_pk_mul_f32 + a raw v_max_f32 (fmaxf: + a canonicalising v_max per value)
+#pragma unroll
+                                for (int j = 0; j < 4; j += 2) {
+                                    const f32x2_t t = f32x2_t{v[j], v[j + 1]} * LRELU_SLOPE;
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(t[0]));
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[j + 1]) : "v"(v[j + 1]), "v"(t[1]));
+                                }
                             }
                             pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
                             pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
@@ -493,7 +505,19 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                             auto r = __builtin_amdgcn_permlane32_swap(pk[0][d], pk[1][d], false, false);
                             o[d] = r[0]; o[2 + d] = r[1];
                         }
-                        if constexpr (HAS_MASK || HAS_ADD) {
+                        if constexpr (HAS_MASK && SMASK && BF) {
+                            // sign byte: bit 2q = low half of dword q, bit 2q+1 = its high half -> nibble 0 = dwords 0-1, nibble 1 = dwords 2-3
+                            const unsigned sb = mb[i][0];
+                            const f32x4 m0 = *reinterpret_cast<const f32x4*>(smem + CD_LUT + ((sb & 15u) << 4));
+                            const f32x4 m1 = *reinterpret_cast<const f32x4*>(smem + CD_LUT + ((sb >> 4) << 4));      // (a zero-extended byte)
+#pragma unroll
+                            for (int q = 0; q < 4; ++q) {
+                                f32x2_t v = f32x2_t{bf_lo(o[q]), bf_hi(o[q])};
+                                if constexpr (HAS_ADD) v = v + f32x2_t{bf_lo(ab[i][q]), bf_hi(ab[i][q])};
+                                v = v * (q < 2 ? f32x2_t{m0[2 * q], m0[2 * q + 1]} : f32x2_t{m1[2 * q - 4], m1[2 * q - 3]});
+                                o[q] = pack_bf16x2(v[0], v[1]);
+                            }
+                        } else if constexpr (HAS_MASK || HAS_ADD) {
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float v0, v1;
@@ -596,9 +620,14 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         for (int h = 0; h < 2; ++h) {
                             float v[4];
 #pragma unroll
-                            for (int j = 0; j < 4; ++j) {
-                                v[j] = acc[mt][nt][(2 * gp + h) * 4 + j];
-                                v[j] = fmaxf(v[j], slope * v[j]);        // LeakyReLU (slope 1: identity)
+                            for (int j = 0; j < 4; ++j) v[j] = acc[mt][nt][(2 * gp + h) * 4 + j];
+                            if constexpr (!BF) {      // LeakyReLU (slope 1: identity); the data-gradient role has none (conv_dma_eligible)
+#pragma unroll
+                                for (int j = 0; j < 4; j += 2) {
+                                    const f32x2_t t = f32x2_t{v[j], v[j + 1]} * slope;
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(t[0]));
+                                    asm("v_max_f32 %0, %1, %2" : "=v"(v[j + 1]) : "v"(v[j + 1]), "v"(t[1]));
+                                }
                             }
                             pk[h][0] = BF ? pack_bf16x2(v[0], v[1]) : pack_f16x2(v[0], v[1]);
                             pk[h][1] = BF ? pack_bf16x2(v[2], v[3]) : pack_f16x2(v[2], v[3]);
@@ -730,6 +759,7 @@ bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size) {
     if (a->c0 % 48 && a->c0 != a->Ktot) return false;           // a chunk never straddles the two sources
     if ((a->M & 7) || (a->Mpad & 31)) return false;
     if (!a->bf16 && (a->mask.p || a->add.p)) return false;      // mask / skip gradient: data-gradient role only
+    if (a->bf16 && a->act) return false;                        // ... which has no LeakyReLU (compile-time in the epilogue)
     if (a->urot.p && (a->bf16 || a->M != 96 || a->Mpad != 96 || a->H != a->W || (a->N & 3) || a->mask.p || a->add.p || a->upsum.p || a->pool.p ||
                       (a->urot.co & 7) || (a->urot.cs & 7) || (long long)(a->N / 4) * a->H * a->W * a->urot.cs * 2 >= (1ll << 31))) return false;
     if (a->upsum.p && (!a->bf16 || a->mask.p || a->add.p || a->upsum_c % 96 || a->upsum_c > a->M)) return false;
