@@ -197,10 +197,40 @@ static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChLa
     }
 }
 
+// two 16-bit channels per instruction on their raw patterns (the max-pool backward pass)
+static __device__ __forceinline__ unsigned ch_pk_add_u16(unsigned a, unsigned b) { unsigned r; asm("v_pk_add_u16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+static __device__ __forceinline__ unsigned ch_pk_max_f16(unsigned a, unsigned b) { unsigned r; asm("v_pk_max_f16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+static __device__ __forceinline__ unsigned ch_pk_nonzero(unsigned a) {      // 0xffff per half that is not 0
+    unsigned t, r;
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(t) : "v"(a), "s"(0x00010001u));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(t), "s"(0xffffffffu));
+    return r;
+}
+static __device__ __forceinline__ unsigned ch_pk_positive(unsigned a) {     // 0xffff per half whose fp16 value is > 0 (as a signed integer: > 0)
+    unsigned t, u, r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(t) : "v"(a));
+    asm("v_pk_min_i16 %0, %1, %2" : "=v"(u) : "v"(t), "s"(0x00010001u));
+    asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(u), "s"(0xffffffffu));
+    return r;
+}
 // 16-byte piece cc of pixel q (row-major at the tensor's own resolution) of a saved tensor
 static __device__ __forceinline__ u32x4_t ch_aux(const ChAux& A, const char* smem, int n, int q, int cc) {
     if (A.where == 1) return *reinterpret_cast<const u32x4_t*>(smem + A.P.off + A.P.org + ((q >> A.P.lw) * A.P.roww + (q & ((1 << A.P.lw) - 1))) * A.P.str + cc * 16);
     return *reinterpret_cast<const u32x4_t*>((const h16*)A.v.p + A.v.co + ((long long)(n << (A.P.lw + A.P.lh)) + q) * A.v.cs + cc * 8);
+}
+
+// the same without a branch: BOTH an LDS read (address 0 of the arena when the tensor is not a plane) and a buffer load (out of range -- zeros,
+// no memory traffic -- when it is not in HBM) are issued and the result is picked by the wave-uniform `where`: with the branch every fetch sits
+// in its own basic block, and the four window fetches of a max-pool entry are four exposed round trips in sequence
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t ch_aux_rsrc(const ChAux& A) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(A.v.p), 0, A.where == 2 ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+}
+static __device__ __forceinline__ u32x4_t ch_aux_nb(const ChAux& A, __amdgpu_buffer_rsrc_t rs, const char* smem, int n, int q, int cc) {
+    const int lofs = A.where == 1 ? A.P.off + A.P.org + ((q >> A.P.lw) * A.P.roww + (q & ((1 << A.P.lw) - 1))) * A.P.str + cc * 16 : 0;
+    const u32x4_t l = *reinterpret_cast<const u32x4_t*>(smem + lofs);
+    const int gofs = (((n << (A.P.lw + A.P.lh)) + q) * A.v.cs + A.v.co + cc * 8) * 2;      // (< 2^31: chain_build checks the tensors' sizes)
+    const u32x4_t g = __builtin_amdgcn_raw_buffer_load_b128(rs, A.where == 2 ? gofs : (int)0x80000000, 0, 0);
+    return A.where == 2 ? g : l;
 }
 
 template <bool BF>
@@ -365,53 +395,78 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
             }
             if (wrote) lds_barrier();
             stamp();
-        } else {
+        } else if constexpr (BF) {      // (compiled into the backward kernel only)
             // ---- SSDN_OP_POOL_BWD: route dpool (P0, pooled resolution) to the window position that held the max, x LeakyReLU' ----
             const ChPlane PQ = L.P0;
             const int Wo = 1 << PQ.lw, Ho = 1 << PQ.lh, H = 2 * Ho;
             const int total = npc << (PQ.lw + PQ.lh);
             unsigned short* dz = (unsigned short*)L.dst.p + L.dst.co;
             const int lw = PQ.lw + 1, lhwf = PQ.lw + PQ.lh + 2;
-            for (int e = tid; e < total; e += CH_THREADS) {
+            // Round 5: this pass was 47 of the backward chain's 115 us -- not its fetches (an entry's four 16-byte fetches were exposed round
+            // trips in sequence, but batching them changed nothing) and not cold code (a second run of the pass took as long): ~2800 scalar-style
+            // instructions per entry (fp16 -> fp32 converts, canonicalising maxima, per-channel compares / selects / bool bookkeeping) on a
+            // single wave per SIMD.  Now two channels per instruction on the raw 16-bit patterns: ~300 per entry, same results bit for bit
+            // (the fp16 maxima and equalities are exact in either width; -0 is folded into +0 first, as == and > treat it).
+            const __amdgpu_buffer_rsrc_t rs_mk = ch_aux_rsrc(L.MK);
+            constexpr int PB = 3;                                // entries of a thread whose window fetches are in flight together
+            for (int e0 = tid; e0 < total; e0 += CH_THREADS * PB) {
+              u32x4_t vv[PB][4];
+#pragma unroll
+              for (int u = 0; u < PB; ++u) {
+                const int e = e0 + u * CH_THREADS < total ? e0 + u * CH_THREADS : tid;      // (past the end: a valid entry again, not used)
                 const int pq = ch_div(e, L.npc_magic), cc = e - pq * npc;
                 const int j = pq & (Wo - 1), i = pq >> PQ.lw;
-                const u16x8 g = __builtin_bit_cast(u16x8, *reinterpret_cast<const u32x4_t*>(ch_px(smem, PQ, i, j) + cc * 16));
                 const int r0 = L.pool_shifted ? 2 * i - 1 : 2 * i;
-                half8 v[4];
-                float m[8];
-                bool taken[8];
-#pragma unroll
-                for (int q = 0; q < 8; ++q) {
-                    m[q] = (L.pool_shifted && r0 < 0) ? 0.f : -65504.f;
-                    taken[q] = false;
-                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int y = r0 + (k >> 1);
-                    if (y < 0) { v[k] = zero_h8(); continue; }
-                    v[k] = __builtin_bit_cast(half8, ch_aux(L.MK, smem, n, (y << lw) + 2 * j + (k & 1), cc));
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) m[q] = fmaxf(m[q], (float)v[k][q]);
+                    vv[u][k] = ch_aux_nb(L.MK, rs_mk, smem, n, ((y < 0 ? 0 : y) << lw) + 2 * j + (k & 1), cc);      // (y < 0: fetched, not looked at)
                 }
-                if (L.pool_shifted && r0 < 0) {                 // the zero pad row is scanned first: if it holds the max, the gradient is dropped
+              }
 #pragma unroll
-                    for (int q = 0; q < 8; ++q) taken[q] = (m[q] == 0.f);
+              for (int u = 0; u < PB; ++u) {
+                const int e = e0 + u * CH_THREADS;
+                if (e >= total) break;
+                const int pq = ch_div(e, L.npc_magic), cc = e - pq * npc;
+                const int j = pq & (Wo - 1), i = pq >> PQ.lw;
+                const u32x4_t g = *reinterpret_cast<const u32x4_t*>(ch_px(smem, PQ, i, j) + cc * 16);
+                const int r0 = L.pool_shifted ? 2 * i - 1 : 2 * i;
+                const bool top = L.pool_shifted && r0 < 0;      // row -1 of a shifted window: the literal 0 of the forward max, scanned first
+                const unsigned topm = top ? 0xffffffffu : 0u;
+                const u32x4_t (&v)[4] = vv[u];
+                u32x4_t o[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    // (no branches on `top`, which differs lane by lane: the pad row enters as two zeros, which change nothing -- the maximum
+                    //  starts at 0 then, and a zero never takes the gradient: `avail` is empty when the maximum is 0)
+                    unsigned x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        x[k] = v[k][d] & ch_pk_nonzero(ch_pk_add_u16(v[k][d], v[k][d]));      // -0 -> +0
+                        if (k < 2) x[k] &= ~topm;
+                    }
+                    unsigned m = top ? 0u : 0xfbfffbffu;                      // -65504 | -65504
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) m = ch_pk_max_f16(m, x[k]);
+                    unsigned avail = ch_pk_nonzero(m) | ~topm;               // the pad row holds the maximum (0): the gradient is dropped
+                    // the gradient times LeakyReLU'(activation): exact for a positive activation, x slope (rounded) otherwise
+                    const unsigned gs = pack_bf16x2(bf_lo(g[d]) * LRELU_SLOPE, bf_hi(g[d]) * LRELU_SLOPE);
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const unsigned ne = ch_pk_nonzero(x[k] ^ m);         // 0xffff where the position does NOT hold the maximum
+                        const unsigned hit = ~ne & avail;                    // ... the first that does takes the gradient
+                        avail &= ne;
+                        const unsigned pos = ch_pk_positive(x[k]);
+                        o[k][d] = ((g[d] & pos) | (gs & ~pos)) & hit;
+                    }
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     const int y = r0 + (k >> 1);
                     if (y < 0) continue;
-                    u16x8 o;
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) {
-                        const float av = (float)v[k][q];
-                        const bool hit = !taken[q] && av == m[q];
-                        if (hit) taken[q] = true;
-                        o[q] = hit ? f2bf(bf2f(g[q]) * lrelu_grad(av)) : (unsigned short)0;
-                    }
                     const int x = 2 * j + (k & 1);
-                    if (L.has_pd) *reinterpret_cast<u16x8*>(ch_px(smem, PD, y, x) + cc * 16) = o;
-                    if (!CH_ABL(c, 2)) st_b8(dz + ((long long)(n << lhwf) + (y << lw) + x) * L.dst.cs + cc * 8, o);
+                    if (L.has_pd) *reinterpret_cast<u32x4_t*>(ch_px(smem, PD, y, x) + cc * 16) = o[k];
+                    if (!CH_ABL(c, 2)) *reinterpret_cast<u32x4_t*>(dz + ((long long)(n << lhwf) + (y << lw) + x) * L.dst.cs + cc * 8) = o[k];
                 }
                 if (L.pool_shifted && i == Ho - 1) {            // shifted pooling never looks at the last row: its gradient is zero
                     const u16x8 z = zero_b8();
@@ -422,6 +477,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                         if (!CH_ABL(c, 2)) st_b8(dz + ((long long)(n << lhwf) + ((H - 1) << lw) + x) * L.dst.cs + cc * 8, z);
                     }
                 }
+              }
             }
             if (L.has_pd) lds_barrier();
             stamp();
@@ -656,11 +712,13 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
         D.lw = ilog2_exact(P.W); D.lh = ilog2_exact(P.H); D.C = P.C;
         return D;
     };
+    bool aux_ok = true;          // a saved tensor in HBM may be fetched through a buffer resource: 32-bit byte offsets
     auto aux = [&](const AuxRef& r) {
         ChAux A{};
         A.v = r.v; A.where = r.where;
         if (r.where == 1) A.P = desc(r.pl);
         else { A.P.lw = ilog2_exact(r.W); A.P.lh = ilog2_exact(r.H); }
+        if (r.where == 2 && ((long long)f->N * r.H * r.W * r.v.cs + r.v.co) * 2 >= (1ll << 31)) aux_ok = false;
         return A;
     };
     memset(out, 0, sizeof(*out));
@@ -701,7 +759,7 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
         const unsigned npc = (unsigned)L.M / 8;
         L.npc_magic = npc <= 1 ? 0u : (unsigned)((0x100000000ull + npc - 1) / npc);
     }
-    return true;
+    return aux_ok;
 }
 
 #undef CH_FAIL

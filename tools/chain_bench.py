@@ -69,13 +69,13 @@ if os.environ.get("CHAIN_BENCH_COLD"):
 if os.environ.get("SSDN_LIB"):
     lib.ssdn_debug_set_trace.argtypes = [C.c_void_p]
     N = 4 * B
-    tr = torch.zeros(N * 64, dtype=torch.int64, device=dev)
+    tr = torch.zeros(N * 96, dtype=torch.int64, device=dev)      # CH_TRACE stamps per workgroup (csrc/conv_chain.hip)
     lib.ssdn_conv_set_chain(1)
     lib.ssdn_debug_set_trace(tr.data_ptr())
     ol.run(current_stream())
     torch.cuda.synchronize()
     lib.ssdn_debug_set_trace(None)
-    t = tr.cpu().view(N, 64)
+    t = tr.cpu().view(N, 96)
     nst = int((t[0] != 0).sum())
     d = (t[:, 1:nst] - t[:, :nst - 1]).double()
     names = ["start: zero, load, barriers"]
@@ -83,6 +83,10 @@ if os.environ.get("SSDN_LIB"):
         nch = ol.args[i].Ktot // 48 if hasattr(ol.args[i], "Ktot") else 0
         names += sum([["L%d chunk %d prologue" % (i, k), "L%d chunk %d 27 K-steps" % (i, k)] for k in range(nch)], [])
         names += ["L%d epilogue" % i, "L%d barrier" % i, "L%d store" % i, "L%d pool" % i]
+    for i in range(best):
+        ar = ol.args[i]
+        print("  op %2d %-10s %s" % (i, next(k for k, v in L.OP.items() if v == full.arr[at + i].type),
+              " ".join("%s=%s" % (f, getattr(ar, f)) for f in ("N", "H", "W", "Ktot", "M", "Mpad", "ntaps", "shifted") if hasattr(ar, f))))
     print("stamps per workgroup: %d; s_memtime ticks (mean over workgroups, min, max):" % nst)
     for i in range(nst - 1):
         print("  %-28s %8.1f %6d %6d" % (names[i] if i < len(names) else "?", float(d[:, i].mean()), int(d[:, i].min()), int(d[:, i].max())))
