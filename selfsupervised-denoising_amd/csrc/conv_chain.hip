@@ -51,9 +51,11 @@ struct ChAux {                                            // a saved tensor an e
     int where, pad_;
 };
 struct ChLoad { ssdn_view src; ChPlane P; int pad_; };
+struct ChNext { const h16* w; int Ktot, npg, ts; };   // the next conv layer with an item for a wave: weights, row length, column groups, tap stride (w == NULL: none)
 struct ChLayer {
     int kind;
     int M, Mpad, Ktot, c0, up0;
+    ChNext nx[4];                  // per wave (chain_build): what first_from(li + 1) used to find by walking the layer table -- a chain of scalar loads
     const h16* w;
     const float* bias;
     ChPlane P0, P1, PD;            // conv: source planes (channels [0, c0) / the rest), output plane.  POOL_BWD: P0 = dpool, PD = dz
@@ -104,8 +106,17 @@ static __device__ __forceinline__ f32x16 ch_mma(half8 a, half8 b, f32x16 c) {
 }
 
 // one 32-row output tile of one layer on this wave: K loop + register epilogue into the output plane
+// what the K loops of a layer read of its descriptor: fetched as ONE batch of scalar loads at the top of the layer (k_conv_chain) -- field by
+// field, where each was used, the way to a layer's first MFMA led through ~25 scalar-load round trips in sequence (~4 K cycles per layer)
+struct ChHot {
+    int M, Mpad, Ktot, c0, up0;
+    const h16* w;
+    const float* bias;
+    ChPlane P0, P1, PD;
+    unsigned tap_dy, tap_dx;
+};
 template <int NPT, bool BF, typename STAMP>
-static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChLayer& L, char* smem, int mt, int pg, int l31, int kh,
+static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChHot& L, char* smem, int mt, int pg, int l31, int kh,
                                                   half8 (&wr)[27], const h16* next_lanep, int next_tapstride, STAMP stamp) {
     const ChPlane P0 = L.P0, P1 = L.P1, PD = L.PD;
     const int HWp = 1 << (PD.lw + PD.lh);
@@ -148,7 +159,7 @@ static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChLa
         int boff[9][NPT];
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-            const int dy = (int)((c.tap_dy >> (3 * t)) & 7u) - 4, dx = (int)((c.tap_dx >> (3 * t)) & 7u) - 4;
+            const int dy = (int)((L.tap_dy >> (3 * t)) & 7u) - 4, dx = (int)((L.tap_dx >> (3 * t)) & 7u) - 4;
 #pragma unroll
             for (int p = 0; p < NPT; ++p)
                 boff[t][p] = cbase + (((py[p] + dy) >> sh) * roww + ((px[p] + dx) >> sh)) * str;
@@ -248,6 +259,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
     };
     stamp();
     const int nlayers = c.nlayers;
+    const unsigned tap_dy = c.tap_dy, tap_dx = c.tap_dx;
     // the wave's work items in order: item it = wave, wave + 4, .. of every conv layer; item -> (32-row tile it / npg, group it % npg
     // of up to four 32-pixel column tiles; npg = 2 for 256-pixel images, else 1)
     auto npg_of = [&](int li) { return c.ly[li].PD.lw + c.ly[li].PD.lh > 7 ? 2 : 1; };
@@ -278,26 +290,40 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
     stamp();
     for (int li = 0; li < nlayers; ++li) {
         const ChLayer& L = c.ly[li];
-        const ChPlane PD = L.PD;
+        // ONE batch of scalar loads for everything up to the layer's last MFMA (the empty asm pins the values here: left alone, every field
+        // is fetched where it is first used, behind a wait of its own)
+        ChHot H;
+        H.M = L.M; H.Mpad = L.Mpad; H.Ktot = L.Ktot; H.c0 = L.c0; H.up0 = L.up0; H.w = L.w; H.bias = L.bias;
+        H.P0 = L.P0; H.P1 = L.P1; H.PD = L.PD; H.tap_dy = tap_dy; H.tap_dx = tap_dx;
+        int kind = L.kind, zb0 = L.zero_bytes[0], zb1 = L.zero_bytes[1], zo0 = L.zero_off[0], zo1 = L.zero_off[1];
+        ChNext NX = L.nx[wave];
+        asm volatile("" : "+s"(H.M), "+s"(H.Mpad), "+s"(H.Ktot), "+s"(H.c0), "+s"(H.up0), "+s"(H.w), "+s"(H.bias), "+s"(kind), "+s"(zb0), "+s"(zb1),
+                     "+s"(zo0), "+s"(zo1), "+s"(NX.w), "+s"(NX.Ktot), "+s"(NX.npg), "+s"(NX.ts));
+        asm volatile("" : "+s"(H.P0.off), "+s"(H.P0.str), "+s"(H.P0.roww), "+s"(H.P0.org), "+s"(H.P1.off), "+s"(H.P1.str), "+s"(H.P1.roww), "+s"(H.P1.org),
+                     "+s"(H.PD.off), "+s"(H.PD.str), "+s"(H.PD.roww), "+s"(H.PD.org), "+s"(H.PD.lw), "+s"(H.PD.lh));
+        const ChPlane PD = H.PD;
         const int lhw = PD.lw + PD.lh;
-        const int npc = L.M >> 3;
-        if (L.zero_bytes[0]) {                                 // output planes of this layer lie where dead planes were: clear (halo = 0)
-#pragma unroll
-            for (int r = 0; r < 2; ++r)
-                for (int z = tid * 16; z < L.zero_bytes[r]; z += CH_THREADS * 16) *reinterpret_cast<half8*>(smem + L.zero_off[r] + z) = zero_h8();
+        const int npc = H.M >> 3;
+        if (zb0) {                                             // output planes of this layer lie where dead planes were: clear (halo = 0)
+            for (int z = tid * 16; z < zb0; z += CH_THREADS * 16) *reinterpret_cast<half8*>(smem + zo0 + z) = zero_h8();
+            for (int z = tid * 16; z < zb1; z += CH_THREADS * 16) *reinterpret_cast<half8*>(smem + zo1 + z) = zero_h8();
             lds_barrier();
         }
-        if (L.kind == CH_CONV) {
-            const int npg = lhw > 7 ? 2 : 1, nitems = (L.Mpad >> 5) * npg;
+        if (kind == CH_CONV) {
+            const int npg = lhw > 7 ? 2 : 1, nitems = (H.Mpad >> 5) * npg;
             for (int it = wave; it < nitems; it += 4) {
-                int nli = li, nit = it + 4;
-                if (nit >= nitems) { nli = first_from(li + 1); nit = wave; }
-                const h16* nlp = nli >= 0 ? lanep_of(nli, nit) : lanep_of(li, it) + (L.Ktot - 48);
-                const int nts = nli >= 0 ? c.ly[nli].Mpad * c.ly[nli].Ktot : L.Mpad * L.Ktot;
+                const int nit = it + 4;
+                // the weight stream's next stop: this wave's next item of the layer, else its first item of the next layer that has one
+                // (ChLayer.nx), else -- the run's last chunk -- itself once more
+                const h16* nlp;
+                int nts;
+                if (nit < nitems) { nlp = H.w + (long long)((nit / npg) * 32 + l31) * H.Ktot + kh * 8; nts = H.Mpad * H.Ktot; }
+                else if (NX.w) { nlp = NX.w + (long long)((wave / NX.npg) * 32 + l31) * NX.Ktot + kh * 8; nts = NX.ts; }
+                else { nlp = H.w + (long long)((it / npg) * 32 + l31) * H.Ktot + kh * 8 + (H.Ktot - 48); nts = H.Mpad * H.Ktot; }
                 const int mt = it / npg, pg = it - mt * npg;
-                if (lhw > 7) chain_tile<4, BF>(c, L, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
-                else if (lhw > 5) chain_tile<2, BF>(c, L, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
-                else chain_tile<1, BF>(c, L, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
+                if (lhw > 7) chain_tile<4, BF>(c, H, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
+                else if (lhw > 5) chain_tile<2, BF>(c, H, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
+                else chain_tile<1, BF>(c, H, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
             }                                                  // (an idle wave keeps the chunk it holds for its next layer)
             stamp();
             lds_barrier();
@@ -759,6 +785,17 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
         const unsigned npc = (unsigned)L.M / 8;
         L.npc_magic = npc <= 1 ? 0u : (unsigned)((0x100000000ull + npc - 1) / npc);
     }
+    // the weight stream's next stop behind each layer, per wave: the first later convolution that has an item for the wave
+    for (int i = 0; i < n; ++i)
+        for (int w = 0; w < 4; ++w) {
+            ChNext& X = out->ly[i].nx[w];
+            X = ChNext{nullptr, 0, 1, 0};
+            for (int j = i + 1; j < n; ++j) {
+                const ChLayer& J = out->ly[j];
+                const int npg = J.PD.lw + J.PD.lh > 7 ? 2 : 1;
+                if (J.kind == CH_CONV && w < (J.Mpad >> 5) * npg) { X = ChNext{J.w, J.Ktot, npg, J.Mpad * J.Ktot}; break; }
+            }
+        }
     return aux_ok;
 }
 
