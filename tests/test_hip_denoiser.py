@@ -103,7 +103,8 @@ def test_training_trajectory(golden_dir, tag, alg, style, mode, ch):
         gd, gr = d.flat_grad.cpu(), _flat_grad_of(d, nets, tr)
         cos = float((gd * gr).sum() / (gd.norm() * gr.norm() + 1e-30))
         agree = float(((gd > 0) == (gr > 0)).float().mean())
-        assert cos >= 0.985 and agree >= 0.95, "iteration %d: gradient cosine %.4f, sign agreement %.4f" % (it, cos, agree)
+        # (measured over the six configurations, round 5: cosine >= 0.9981, sign agreement >= 0.980, update cosine >= 0.965)
+        assert cos >= 0.997 and agree >= 0.97, "iteration %d: gradient cosine %.4f, sign agreement %.4f" % (it, cos, agree)
         d.optimizer_step(lr)
         tr.steps += 1
         with torch.no_grad():
@@ -112,7 +113,7 @@ def test_training_trajectory(golden_dir, tag, alg, style, mode, ch):
         torch.cuda.synchronize()
         du, ru = d.flat.cpu() - start, _flat_of(d, nets, tr) - start
         ucos = float((du * ru).sum() / (du.norm() * ru.norm() + 1e-30))
-        assert ucos >= 0.9, "iteration %d: Adam update cosine %.4f" % (it, ucos)
+        assert ucos >= 0.95, "iteration %d: Adam update cosine %.4f" % (it, ucos)
         assert float(du.abs().max()) <= lr * 3.5       # |m_hat/sqrt(v_hat)| <= ~3.2 for betas (0.9, 0.99) in the first steps
 
 

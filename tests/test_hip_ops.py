@@ -396,9 +396,12 @@ def test_net_backward_end_to_end(cin, cout, bs, B, P):
                            ("b", slice(l.b_off, l.b_off + l.M), leaves[l.name + ".bias"].grad)):
             a, ai = gh[sl], it.grads[sl]
             cos = float((a * rg).sum() / (a.norm() * rg.norm() + 1e-30))
-            if not _rel(a, ai) <= 0.15:
+            # bounds = 1.5 x the worst layer measured on the device (round 5: 0.058 vs the fp16 interpreter, 0.087 / cosine 0.9965 vs the fp32
+            # oracle -- bf16 gradients of 1e-3-sized seeds through 20 layers at batch 2; the tight statements are the teacher-forced
+            # per-op cases above and the full-size fixtures of tests/test_hip_fullsize.py)
+            if not _rel(a, ai) <= 0.09:
                 bad.append("%s.%s vs fp16 interpreter: rel %.3e" % (l.name, nm, _rel(a, ai)))
-            if not (_rel(a, rg) <= 0.15 and cos >= 0.99):
+            if not (_rel(a, rg) <= 0.13 and cos >= 0.995):
                 bad.append("%s.%s vs fp32 oracle: rel %.3e cos %.5f" % (l.name, nm, _rel(a, rg), cos))
     assert not bad, "\n".join(bad)
 
