@@ -320,10 +320,12 @@ def run_rank(args):
     for i in range(args.warmup):
         step(i)
 
-    # roofline leg: HIP events around the launches of the dominant kernel, k_cdma<3,*> (the 96-output-channel 3x3 layers at
+    # roofline leg: HIP events of launches of the dominant kernel, k_cdma<3,*> (the 96-output-channel 3x3 layers at
     # 32x32 and 64x64 pixels, forward and data-gradient roles: 8 launches per step, 60 % of the step's flops), on the launch
-    # stream, during the timed steps.  An event pair costs ~10 us of stream time (it serialises what would be back-to-back
-    # kernels), so only every 9th launch is bracketed (9 is coprime to the 8 launches of a step: the sample rotates over all eight layers).
+    # stream, during the timed steps.  Since round 5 the two events of a sample ride on the sampled launch's own dispatch
+    # (hipExtLaunchKernelGGL start / stop event, csrc/common.h::SSDN_LAUNCH): the kernel's duration, within ~5 % of the rocprofv3
+    # kernel trace (two hipEventRecord calls around the launch measured ~10 us more per sample and cost the stream as much).
+    # Every 9th launch is sampled (9 is coprime to the 8 launches of a step: the sample rotates over all eight layers).
     PROF_STRIDE = 9
     if lib is not None:
         prof_kind = L.PROF["cdma_mt3"]
@@ -473,7 +475,7 @@ def run_rank(args):
                                "traffic_unit": "HBM-side bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE from separate --pmc passes over this "
                                                "command; NOT measured in this run: %s" % traffic_src,
                                "algorithmic_bytes_per_launch": int(by.value / max(1, cnt.value)),
-                               "launches": int(cnt.value), "sampling": "every %dth launch of the timed region" % PROF_STRIDE, "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 3),
+                               "launches": int(cnt.value), "sampling": "every %dth launch of the timed region; the two HIP events of a sample ride on the sampled launch's own dispatch (hipExtLaunchKernelGGL start / stop event: the kernel's duration as a kernel trace reports it)" % PROF_STRIDE, "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 3),
                                "kernel_time_share": round(PROF_STRIDE * ms.value / 1e3 / dt, 4)}
             res["families"] = families
             # the time-dominant family next to the flop-dominant one: the weight gradients of the whole network,

@@ -8,6 +8,8 @@
 static thread_local char g_err[512] = "";
 thread_local hipEvent_t g_ssdn_stop_event = nullptr;
 thread_local bool g_ssdn_stop_used = false;
+thread_local hipEvent_t g_ssdn_prof_start = nullptr, g_ssdn_prof_stop = nullptr;
+thread_local bool g_ssdn_prof_used = false;
 
 int ssdn_set_error(const char* fmt, ...) {
     va_list ap;
@@ -27,7 +29,10 @@ struct ProfSlot {
     long long seen = 0;      // launches of the family since enable
     int stride = 1;          // every stride-th launch is bracketed (an event pair costs ~10 us of stream time)
     bool armed = false;      // the launch in flight between prof_begin and prof_end is a sampled one
+    bool attached = false;   // ... and its two events ride on the kernel's dispatch (SSDN_LAUNCH) instead of being recorded around it
 };
+// kinds whose bracket holds exactly ONE SSDN_LAUNCH (csrc/conv_dma.hip::cd_launch, csrc/gemm_dma.hip::gd_launch)
+static bool prof_single_launch(int id) { return id == SSDN_PROF_CDMA_MT3 || id == SSDN_PROF_CDMA_MT21 || id == SSDN_PROF_GEMM; }
 static ProfSlot g_prof[SSDN_PROF_KINDS];
 
 void prof_begin(int id, hipStream_t s) {
@@ -37,13 +42,24 @@ void prof_begin(int id, hipStream_t s) {
     const bool pick = p.seen++ % p.stride == 0;
     if (!pick || p.used + 2 > p.ev.size()) return;
     p.armed = true;
-    (void)hipEventRecord(p.ev[p.used], s);
+    // (a launch that already carries another lane's stop event keeps the recorded bracket)
+    p.attached = prof_single_launch(id) && !g_ssdn_stop_event;
+    if (p.attached) {
+        g_ssdn_prof_start = p.ev[p.used];
+        g_ssdn_prof_stop = p.ev[p.used + 1];
+        g_ssdn_prof_used = false;
+    } else (void)hipEventRecord(p.ev[p.used], s);
 }
 void prof_end(int id, hipStream_t s, double flops, double bytes) {
     ProfSlot& p = g_prof[id];
     if (!p.on || !p.armed) return;
     p.armed = false;
-    (void)hipEventRecord(p.ev[p.used + 1], s);
+    if (p.attached) {
+        const bool used = g_ssdn_prof_used;
+        g_ssdn_prof_start = g_ssdn_prof_stop = nullptr;
+        g_ssdn_prof_used = false;
+        if (!used) return;                                     // (no SSDN_LAUNCH in the bracket: no sample)
+    } else (void)hipEventRecord(p.ev[p.used + 1], s);
     p.used += 2;
     p.flops += flops;
     p.bytes += bytes;

@@ -89,11 +89,20 @@ static __device__ __forceinline__ half8 zero_h8() {
 // producing stream a 5-14 us bubble behind every such kernel (a barrier packet the next dispatch queues behind).
 extern thread_local hipEvent_t g_ssdn_stop_event;
 extern thread_local bool g_ssdn_stop_used;
+// The in-stream profiler's sample of a launch (prof_begin .. prof_end, api.hip) rides on the kernel's own dispatch the same way: start and
+// stop event of hipExtLaunchKernelGGL are the dispatch's begin / end timestamps -- the kernel's duration as the rocprofv3 kernel trace
+// reports it.  (Two hipEventRecord calls around the launch measured ~10 us more per sample: the records' own stream time.)
+extern thread_local hipEvent_t g_ssdn_prof_start, g_ssdn_prof_stop;
+extern thread_local bool g_ssdn_prof_used;
 #define SSDN_LAUNCH(kernel, grid, block, lds, stream, ...)                                                                       \
     do {                                                                                                                         \
         if (g_ssdn_stop_event) {                                                                                                 \
             hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, g_ssdn_stop_event, 0, __VA_ARGS__);                 \
             g_ssdn_stop_used = true;                                                                                             \
+        } else if (g_ssdn_prof_start) {                                                                                          \
+            hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, g_ssdn_prof_start, g_ssdn_prof_stop, 0, __VA_ARGS__);        \
+            g_ssdn_prof_start = nullptr;                                                                                         \
+            g_ssdn_prof_used = true;                                                                                             \
         } else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                                                \
     } while (0)
 
