@@ -116,6 +116,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_conv_thin(ssdn_conv_args a, int 
     constexpr int OSTR = MT * 64 + 16;
     char* reg = smem + (((HH * HW + 1) * 8 + 15) & ~15) + wave * (32 * OSTR);
     const int npc = a.M >> 3;
+    const unsigned npc_magic = (unsigned)((0x100000000ull + npc - 1) / npc);
     h16* dst = (h16*)a.dst.p + a.dst.co;
     const int zoff = HH * HW * 8;
 #pragma unroll 2
@@ -146,7 +147,13 @@ __global__ __launch_bounds__(CT_THREADS) void k_conv_thin(ssdn_conv_args a, int 
             for (int g = 0; g < 4; ++g) {
                 float v[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = lrelu(acc[mt][g * 4 + j]);
+                for (int j = 0; j < 4; ++j) v[j] = acc[mt][g * 4 + j];
+#pragma unroll
+                for (int j = 0; j < 4; j += 2) {      // LeakyReLU = max(v, slope v): v_pk_mul_f32 + a raw v_max_f32 (round 5; was compare + multiply + select per value)
+                    const f32x2_t t = f32x2_t{v[j], v[j + 1]} * LRELU_SLOPE;
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v[j]) : "v"(v[j]), "v"(t[0]));
+                    asm("v_max_f32 %0, %1, %2" : "=v"(v[j + 1]) : "v"(v[j + 1]), "v"(t[1]));
+                }
                 u32x2_t o;
                 o[0] = pack_f16x2(v[0], v[1]);
                 o[1] = pack_f16x2(v[2], v[3]);
@@ -156,14 +163,21 @@ __global__ __launch_bounds__(CT_THREADS) void k_conv_thin(ssdn_conv_args a, int 
         __builtin_amdgcn_wave_barrier();
         const long long pix0 = (long long)(n * a.H + y0 + (((wave * 8 + i) * 32) >> 6)) * a.W + x0 + (((wave * 8 + i) * 32) & 63);
         for (int e = lane; e < 32 * npc; e += 64) {
-            const int p = e / npc, cc = e - p * npc;
+            const int p = (int)__umulhi((unsigned)e, npc_magic), cc = e - p * npc;      // e / npc (exact for e < 2^16: magic = ceil(2^32 / npc))
             const u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + (i & 1) * (4 * 32 * OSTR) + p * OSTR + cc * 16);
             *reinterpret_cast<u32x4_t*>(dst + (pix0 + p) * a.dst.cs + cc * 8) = o;
             if (a.sign_out) {      // LeakyReLU sign byte of the piece (ssdn_conv_args.sign_out): bit q = (channel q > 0), on the raw fp16 halves
-                unsigned sb = 0;
+                // min(max(h, 0), 1) per half on the raw 16-bit patterns, the eight 0/1 halves merged by shifts (k_cdma's form: 13 instructions)
+                unsigned rq[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    sb |= ((int)(short)(o[q] & 0xffffu) > 0 ? 1u : 0u) << (2 * q) | (((int)o[q] >> 16) > 0 ? 1u : 0u) << (2 * q + 1);
+                for (int q = 0; q < 4; ++q) {
+                    unsigned t0;
+                    asm("v_pk_max_i16 %0, %1, 0" : "=v"(t0) : "v"(o[q]));
+                    asm("v_pk_min_i16 %0, %1, %2" : "=v"(rq[q]) : "v"(t0), "s"(0x00010001u));
+                }
+                const unsigned t01 = (rq[1] << 2) | rq[0], t23 = (rq[3] << 2) | rq[2];
+                const unsigned t = (t23 << 4) | t01;              // bits 0,2,4,6: low halves; 16,18,20,22: high halves
+                const unsigned sb = t | (t >> 15);
                 ((unsigned char*)a.sign_out)[(pix0 + p) * npc + cc] = (unsigned char)sb;
             }
         }
