@@ -439,13 +439,18 @@ def run_rank(args):
             pass
         # the newest committed PMC summary of THIS kernel (tools/pmc_traffic.sh) -- quoted only if it was collected with the library this
         # run loaded (lib_sha256 in the summary): a figure of another build says nothing about the benchmarked binary
-        for cand in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_traffic\.json$", f)), reverse=True):
+        cands = [f for f in os.listdir(os.path.join(ROOT, "profiles")) if re.match(r"r\d+_traffic\.json$", f)]
+        for cand in sorted(cands, key=lambda f: int(re.match(r"r(\d+)_", f).group(1)), reverse=True):      # newest round first (r10 > r9)
+            if lib_sha is None:
+                traffic_src = "the loaded library could not be read back for its sha256: no PMC summary quoted"
+                break
             try:
                 with open(os.path.join(ROOT, "profiles", cand)) as f:
                     tj = json.load(f)
                 if tj.get("lib_sha256") != lib_sha:
-                    traffic_src = "profiles/%s describes another build of the library (its lib_sha256 differs): not quoted" % cand
-                    break
+                    if traffic_src is None:
+                        traffic_src = "profiles/%s describes another build of the library (its lib_sha256 differs): not quoted" % cand
+                    continue        # (an older summary may still be the one of this build)
                 traffic = int(tj["hbm_bytes_per_launch"])
                 traffic_src = "profiles/%s (collected at %s, same library build: sha256 %s...)" % (cand, tj.get("collected_at", "?"), lib_sha[:12])
                 break

@@ -22,7 +22,7 @@ sys.path.insert(0, HERE)
 import ref_shim  # noqa: E402
 import restate as R  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("SSDN_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")      # (override: tests/test_oracle_golden.py regenerates into a scratch directory)
 os.makedirs(OUT, exist_ok=True)
 torch.set_num_threads(8)
 

@@ -19,7 +19,7 @@ import ref_shim  # noqa: E402
 import restate as R  # noqa: E402
 import fullsize as F  # noqa: E402
 
-OUT = os.path.join(os.path.dirname(HERE), "tests", "golden")
+OUT = os.environ.get("SSDN_GOLDEN_OUT") or os.path.join(os.path.dirname(HERE), "tests", "golden")      # (override: tests/test_oracle_golden.py regenerates into a scratch directory)
 torch.set_num_threads(8)
 
 

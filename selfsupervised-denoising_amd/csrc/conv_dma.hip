@@ -37,6 +37,7 @@
 #include "common.h"
 #include <cstdlib>
 #include <type_traits>
+#include <utility>
 
 // Tuning aids (ablation bits, phase stamps, weight replication) are compiled in only with -DSSDN_TUNING (`make TUNING=1`; tools/cdma_probe.sh
 // and the trace mode of tools/conv_bench.py need such a build): as run-time flags they cost ~40 scalar instructions and 10 branches PER STEP of a kernel that is
@@ -49,6 +50,17 @@
 #define CD_TUNING 0
 #endif
 
+// A/B aid (EXTRA=-DCD_MOVE_BARRIER=0|1): the step barrier in front of the step's last K-step, the next step's first fragment reads behind it
+#ifndef CD_EXP_BARRIER
+#define CD_EXP_BARRIER 0
+#endif
+#ifndef CD_DEPHASE
+#define CD_DEPHASE 0
+#endif
+#ifndef CD_MOVE_BARRIER
+#define CD_MOVE_BARRIER 0
+#endif
+
 namespace {
 
 constexpr int CD_TBYTES = 31744;   // 18 x 18 pixels x 96 B = 31104, + 640 B that hold the bias (see below)
@@ -57,13 +69,16 @@ struct CdAux {
     int m_base, m_cnt;          // output channels [m_base, m_base + m_cnt) of this launch (m_cnt % 8 == 0, <= MT*32)
     int padT, padL, rev;        // halo origin (y0 - padT, x0 - padL); weight tap of halo offset (i,j): rev ? 8-(3i+j) : 3i+j
     int tiles_x, tiles_y;       // 16x16 tiles per image
-    int segs, tps;              // a strip (image, tile column) is cut into `segs` work items of `tps` consecutive tiles
+    int segs, tps;              // a strip (image, tile column) is cut into `segs` work items of `tps` consecutive tiles (segs: a power of two)
+    int segs_sh;                // log2(segs)
+    unsigned tx_magic;          // ceil(2^32 / tiles_x): strip / tiles_x as one s_mul_hi_u32 (tiles_x > 1; strips and tiles_x < 2^16)
     int nitems, xcd_map;
     int nfull, tail16;          // 48-channel chunks, then an optional 16-channel chunk
     int ablate;                 // tuning aid (env SSDN_CDMA_ABLATE, read once): 1 no MFMA, 2 no weight DMA, 4 no tile DMA, 8 no epilogue,
                                 // 16 no DMA waits, 32 no step barriers (16, 32: wrong results, timing only), 64 epilogue stores dropped by a
                                 // zero-size buffer resource (the arithmetic and the issue slots stay)
     int wrep;                   // experiment (env SSDN_CDMA_WREP): the weight tensor exists in `wrep` consecutive copies
+    int dephase;                // the second workgroup of a CU starts `dephase` x ~0.5 us late (0: together; see k_cdma)
     unsigned long long* trace;  // tuning aid (ssdn_debug_set_trace): s_memtime stamps, 32 per workgroup
 };
 
@@ -77,11 +92,9 @@ __device__ __forceinline__ void dma16(unsigned lds_addr, int voff, __amdgpu_buff
 }
 
 template <bool BF>
-__device__ __forceinline__ f32x16 cd_mma(half8 av, half8 bv, f32x16 c) {
-    if constexpr (BF)
-        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
-    else
-        return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
+__device__ __forceinline__ void cd_mma(f32x16& c, half8 av, half8 bv) {
+    if constexpr (BF) c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, av), __builtin_bit_cast(bf16x8, bv), c, 0, 0, 0);
+    else c = __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
 }
 
 // ---- one step on the matrix cores: tap (I, J) of a KS*16-channel chunk ---------------------------------------------------------
@@ -117,12 +130,31 @@ template <int MT, bool BF>
 __device__ __forceinline__ void cd_mmas(f32x16 (&acc)[MT][2], const half8 (&aq)[MT], const half8 (&bq)[2]) {
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        acc[mt][0] = cd_mma<BF>(aq[mt], bq[0], acc[mt][0]);
-        acc[mt][1] = cd_mma<BF>(aq[mt], bq[1], acc[mt][1]);
+        cd_mma<BF>(acc[mt][0], aq[mt], bq[0]);
+        cd_mma<BF>(acc[mt][1], aq[mt], bq[1]);
     }
 }
 
 struct CdTile { int n, y0, x0; };
+
+// how waves 0-1 share the 1 KiB pieces of one (tap, chunk) weight slice: each wave's pieces sit behind ONE M0 / soffset pair and differ by the
+// instruction's immediate offset (0 .. 3072: the immediate advances the global AND the LDS address, and the slice is the LDS image)
+template <int MT, bool FULL>
+struct CdWSplit {
+    static constexpr int nq = FULL ? MT * 3 : MT;                       // pieces of the slice (48-channel / 16-channel chunk)
+    static constexpr int NB = (nq + 1) / 2 > 4 ? 4 : (nq + 1) / 2;      // pieces per wave
+    static constexpr bool extra = nq > 2 * NB;                          // MT = 3, 48 channels: piece 8 -- wave 0 fetches it
+    static constexpr int b1 = extra ? NB : nq - NB;                     // first piece of wave 1 (an overlap re-fetches the same bytes)
+};
+template <int N> using cd_ic = std::integral_constant<int, N>;
+template <class F, int... Is>
+__device__ __forceinline__ void cd_static_for_impl(F& f, std::integer_sequence<int, Is...>) { (f(cd_ic<Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void cd_static_for(F&& f) { cd_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
+template <int IMM>
+__device__ __forceinline__ void dma16i(unsigned lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cd_lds_ptr)(size_t)lds_addr, 16, voff, soff, IMM, 0);
+}
 
 }  // namespace
 
@@ -137,12 +169,13 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WROWS = MT * 32;
     constexpr int WBYTES = WROWS * 96;        // one (tap, 48-channel chunk) weight slice
-    constexpr int NWQ = MT * 3;               // 1 KiB DMA instructions per 48-channel weight slice; the 16-channel slice has MT
     constexpr int OSTR = MT * 64 + 16;        // epilogue: LDS bytes per pixel (16 B x odd: conflict-free ds_write_b128)
     constexpr int NEK = MT * 2;               // epilogue: 64-lane 16-byte row instructions per 32-pixel pass
     constexpr bool HAS_MASK = (EPI & 1) != 0, HAS_ADD = (EPI & 2) != 0, HAS_UPS = (EPI & 4) != 0, UROT = (EPI & 8) != 0;
     constexpr bool SOUT = (EPI & 16) != 0, SMASK = (EPI & 32) != 0;
     constexpr int NUK = (8 * MT * 4 + 63) / 64;   // upsum: 64-lane instructions per pass (8 pixels x cpp pieces)
+    constexpr int G = 2 * MT;                 // MFMAs of a K-step = gaps the loader pieces of a step are dealt to
+    constexpr bool MOVE = CD_MOVE_BARRIER != 0;
     const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, kh = lane >> 5;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const bool wload = w < 2;                 // waves 0-1 fetch weights, waves 2-3 fetch tiles
@@ -154,135 +187,131 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // ---- work items of this workgroup ---------------------------------------------------------------------------------
     // xcd_map: workgroups are dealt to the 8 XCDs round-robin by id and each XCD has its own L2 -> XCD x walks the contiguous
     // item range [x*I/8, (x+1)*I/8), so neighbouring strips (which share halo columns) meet in one L2.
-    const int G = gridDim.x;
+    const int G_ = gridDim.x;
     int it_first, it_stride, it_end;
     if (x.xcd_map) {
         const int i8 = x.nitems >> 3, xcd = blockIdx.x & 7;
-        it_first = xcd * i8 + (blockIdx.x >> 3); it_stride = G >> 3; it_end = (xcd + 1) * i8;
+        it_first = xcd * i8 + (blockIdx.x >> 3); it_stride = G_ >> 3; it_end = (xcd + 1) * i8;
     } else {
-        it_first = blockIdx.x; it_stride = G; it_end = x.nitems;
+        it_first = blockIdx.x; it_stride = G_; it_end = x.nitems;
     }
     if (it_first >= it_end) return;
 
     // ---- per-lane constants ---------------------------------------------------------------------------------------------
-    const int xl = l31 & 15, tyl = 4 * w + (l31 >> 4);
-    // B fragments (input pixels): lane = pixel (tyl, xl) of the tile, k half kh; tap row parity picks the swizzled piece
-    const int par = tyl & 1;
-    const int bE48 = tyl * 1728 + xl * 96 + ((kh ^ par) << 4), bO48 = tyl * 1728 + xl * 96 + ((kh ^ par ^ 1) << 4);
-    const int bE16 = tyl * 576 + xl * 32 + ((kh ^ par) << 4), bO16 = tyl * 576 + xl * 32 + ((kh ^ par ^ 1) << 4);
-    // A fragments (weights): lane = row l31 (+32 mt), k half kh
-    const int asw = (kh ^ ((l31 >> 3) & 1)) << 4;
-    const int aB48 = l31 * 96 + asw, aB16 = l31 * 32 + asw;
-    constexpr int NWU = (NWQ + 1) / 2;       // weight DMA instructions per wave per slice (waves 0-1, q = lw + 2u)
-    // epilogue: row instruction k covers 16-byte pieces [64k, 64k+64) of this wave's 32-pixel pass; piece p = (pixel p / cpp,
-    // piece p % cpp); pixel px = (row px >> 4 of the pass, column px & 15)
+    // (few on purpose: with two fragment sets and 96 accumulator registers the allocator has ~40 registers for everything else; what the
+    //  16-channel chunk and the epilogue need is re-derived from the lane id where it is used)
+    // B fragments (input pixels): lane = pixel (tyl, xl) of the tile, k half kh; tap row parity picks the swizzled piece (the odd rows' base
+    // is the even rows' ^ 16).  A fragments (weights): lane = row l31 (+32 mt), k half kh
+    const int bE48 = (4 * w + (l31 >> 4)) * 1728 + (l31 & 15) * 96 + ((kh ^ ((l31 >> 4) & 1)) << 4);
+    const int aB48 = l31 * 96 + ((kh ^ ((l31 >> 3) & 1)) << 4);
     const int cpp = x.m_cnt >> 3;
-    int e_pc[NEK];     // pixel | piece << 8, or -1
-#pragma unroll
-    for (int k = 0; k < NEK; ++k) {
-        const int p = k * 64 + lane;
-        const int px = p / cpp, c = p - px * cpp;
-        e_pc[k] = p < 32 * cpp ? (px | (c << 8)) : -1;
-    }
 
     // ---- buffer resources ---------------------------------------------------------------------------------------------------
     // (num_records = 2 GiB for every resource: all tensors are smaller -- checked by the launcher -- and the one out-of-range
     //  offset used, 0x80000000, still reads as zero; constants cost no live SGPRs)
     const __amdgpu_buffer_rsrc_t rs_wc = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wc), 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const int H0 = a.up0 ? (a.H >> 1) : a.H, W0 = a.up0 ? (a.W >> 1) : a.W;
-    const __amdgpu_buffer_rsrc_t rs_s0 = __builtin_amdgcn_make_buffer_rsrc(a.src0.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
-    const __amdgpu_buffer_rsrc_t rs_s1 = __builtin_amdgcn_make_buffer_rsrc(a.src1.p ? a.src1.p : a.src0.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const int nch = x.nfull + x.tail16;
 
     int tr_i = 0;
     auto stamp = [&]() __attribute__((always_inline)) {
         if (CD_TUNING && x.trace && tid == 0 && tr_i < 32) x.trace[(size_t)blockIdx.x * 32 + tr_i++] = __builtin_amdgcn_s_memtime();
     };
-    // waves 0-1: DMA of the weight slice (chunk c, halo tap tseq = 3i+j) into weight buffer `wpar`
-    // byte offset of the (tap, chunk) slice in the chunk-major copy = wchunk(c) + wt0 + tseq * wts  (tseq = 3i+j of the halo tap; the
-    // mirrored window of the data-gradient role walks the taps backwards)
+
+    // ---- waves 0-1: the weight stream --------------------------------------------------------------------------------------------
+    // byte offset of the (tap, chunk) slice in the chunk-major copy = wchunk(c) + tseq * wts  (tseq = 3i+j of the halo tap; the
+    // mirrored window of the data-gradient role walks the taps backwards).  The slice IS the LDS image (ssdn_conv_args.wc): linear
+    // 1 KiB pieces, every lane at +16 lane.
     const int wtap = a.Mpad * a.Ktot * 2;
     const int wt0 = x.rev ? 8 * wtap : 0, wts = x.rev ? -wtap : wtap;
+    const int wvoff = lane * 16;
+    const bool lw0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;       // (its own scalar compare: not the lane mask `wload` and `lw` share)
     auto wchunk = [&](int c) __attribute__((always_inline)) {
         return __builtin_amdgcn_readfirstlane((c * 48 * a.Mpad + x.m_base * (c < x.nfull ? 48 : 16)) * 2 + wt0);
     };
-    auto issue_w = [&](int wcb, bool full, int tseq, int wpar) __attribute__((always_inline)) {
+    // piece j of this wave's share of a slice: d / so = LDS address / byte offset of the wave's first piece
+    auto wpiece = [&](auto FULLc, auto Jc, unsigned d, int so) __attribute__((always_inline)) {
+        using S = CdWSplit<MT, decltype(FULLc)::value != 0>;
+        constexpr int j = decltype(Jc)::value;
         if (CD_ABL(x, 2)) return;
-        const unsigned dst = wlds0 + wpar * WBYTES;
-        // chunk-major pre-swizzled copy [tap][chunk][Mpad][kc] (ssdn_conv_args.wc, mandatory for this kernel): the slice IS the
-        // LDS image -> linear 1 KiB pieces
-        const int sbase = wcb + tseq * wts;
-        const int nq = full ? NWQ : MT;
-#pragma unroll
-        for (int u = 0; u < NWU; ++u)
-            if (lw + 2 * u < nq) dma16(dst + (lw + 2 * u) * 1024, lane * 16, rs_wc, sbase + (lw + 2 * u) * 1024);
+        if constexpr (j < S::NB) dma16i<j * 1024>(d, wvoff, rs_wc, so);
+        else if constexpr (S::extra) { if (lw0) dma16i<0>(d + 2 * S::NB * 1024, wvoff, rs_wc, so + 2 * S::NB * 1024); }
     };
-    // waves 2-3: DMA of halo-tile ROWS.  A row of a 48-channel chunk is 18 pixels x 6 pieces = 108 pieces = two instructions of
-    // 54 active lanes (the other 10 are EXEC-masked: masked lanes write nothing); a row of the 16-channel chunk is 36 pieces =
-    // one instruction.  Everything about a ROW is wave-uniform (image row, validity, base address -> SGPRs / soffset); per lane
-    // only the (pixel, piece) -> byte offset inside the row remains, the same for every row of a (tile, chunk) up to the
-    // swizzle's row parity: prepared once per chunk (row_lane), so a row item costs ~10 scalar and 1 vector
-    // instruction.  (First version: ~60 instructions per item, which made the tile waves the slow ones at every barrier.)
-    // row item r of a chunk: 48-ch: halo row r >> 1, half r & 1 (36 items); 16-ch: halo row r (18 items).  Wave lw takes r = lw + 2u.
+    auto wbase = [&](bool full) __attribute__((always_inline)) {      // byte offset of this wave's first piece inside a slice
+        return lw ? (full ? CdWSplit<MT, true>::b1 : CdWSplit<MT, false>::b1) * 1024 : 0;
+    };
+    auto wslice = [&](bool full, unsigned dbuf, int sl) __attribute__((always_inline)) {     // a whole slice (start-up, chunk change)
+        const int wb = wbase(full);
+        if (full) cd_static_for<CdWSplit<MT, true>::NB + 1>([&](auto jc) { wpiece(cd_ic<1>{}, jc, dbuf + wb, sl + wb); });
+        else cd_static_for<CdWSplit<MT, false>::NB + 1>([&](auto jc) { wpiece(cd_ic<0>{}, jc, dbuf + wb, sl + wb); });
+    };
+
+    // ---- waves 2-3: the halo-tile stream -----------------------------------------------------------------------------------------
+    // A halo row of a 48-channel chunk is 18 pixels x 6 pieces = 108 pieces.  Wave 0 of the role fetches row pieces 0..63, wave 1 pieces
+    // 44..107 (ALL 64 lanes active: no EXEC juggling; the 20 pieces both fetch are the same bytes); a row of the 16-channel chunk is 36
+    // pieces = one instruction of 36 lanes, rows dealt alternately.  Everything about a ROW is wave-uniform and lives on the scalar unit
+    // as RUNNING values (soffset of the next row, its increment after an even / odd halo row -- an up-sampled source advances every
+    // other row); per lane only the (pixel, piece) -> byte offset inside a source row remains, one register per swizzle parity,
+    // prepared once per chunk.  A row item is: s_add (soffset), s_add (M0), the DMA -- and, for the halo rows that can fall off the
+    // image (0, 1, 16, 17), a compare + select of the out-of-range offset (zero fill by the range check).
     // LDS piece p of a row holds (pixel p / PP, channel piece (p % PP) ^ (hy & 1)): the swizzle is applied on the SOURCE side.
-    // byte offset of this lane's 16 bytes inside a source row of (tile t, chunk c), for an even (pr = 0) / odd halo row, or OOB.
-    // (A wave always fetches the same half of the 48-channel rows: half = lw.)
-    auto row_lane = [&](const CdTile& t, int c, int pr) __attribute__((always_inline)) {
-        const int k0 = c * 48;
-        const bool from0 = k0 < a.c0;
-        const bool up = from0 && a.up0;
-        const int cs = from0 ? a.src0.cs : a.src1.cs;
-        const bool full = c < x.nfull;
-        const int hp48 = lane / 6;
-        const int hx = full ? hp48 + 9 * lw : lane >> 1;
-        const int cc = full ? lane - hp48 * 6 : lane & 1;
-        const int xx = t.x0 - x.padL + hx;
-        const bool ok = (unsigned)xx < (unsigned)a.W;
-        const int xs = up ? xx >> 1 : xx;
-        return ok ? (xs * cs + (cc ^ pr) * 8) * 2 : (int)0x80000000;
-    };
-    // everything about the rows of one (tile, chunk) that does not depend on the row: prepared ONCE per chunk, on the scalar unit
-    // (plain scalars, not a struct: in some instantiations a struct of them was placed in scratch)
-    auto row_ctx = [&](const CdTile& t, int c, int tpar, bool& o_rs, int& o_rbase, int& o_rstride, int& o_ybs, int& o_ush, unsigned& o_dst) __attribute__((always_inline)) {
+    __amdgpu_buffer_rsrc_t rs_t = rs_wc;
+    int t_so = 0, t_incA = 0, t_incB = 0, t_ybs = 0, rlE = 0, rlO = 0;
+    unsigned t_tb = 0;
+    // prepare the rows of (tile (tn, ty0, tx0), chunk c) for tile buffer `tbi`; live = false: a resource of size 0 (every lane out of range)
+    auto tile_setup = [&](int tn, int ty0, int tx0, int c, int tbi, bool live) __attribute__((always_inline)) {
         const int k0 = c * 48;
         const bool from0 = k0 < a.c0;
         const bool up = from0 && a.up0;
         const int cs = from0 ? a.src0.cs : a.src1.cs;
         const int cbase = from0 ? a.src0.co + k0 : a.src1.co + k0 - a.c0;
         const int Hs = up ? H0 : a.H, Ws = up ? W0 : a.W;
-        // (readfirstlane: the values ARE wave-uniform; saying so once per chunk keeps the nine steps' row arithmetic on the scalar unit)
-        o_rs = from0;
-        o_rstride = __builtin_amdgcn_readfirstlane(Ws * cs * 2);
-        o_rbase = __builtin_amdgcn_readfirstlane((t.n * Hs * Ws * cs + cbase) * 2);
-        o_ybs = __builtin_amdgcn_readfirstlane(t.y0 - x.padT);
-        o_ush = up ? 1 : 0;
-        o_dst = __builtin_amdgcn_readfirstlane(tlds0 + tpar * CD_TBYTES);
+        const bool full = c < x.nfull;
+        // (readfirstlane: the values ARE wave-uniform; saying so keeps the row arithmetic on the scalar unit)
+        const int rstride = __builtin_amdgcn_readfirstlane(Ws * cs * 2);
+        const int rbase = __builtin_amdgcn_readfirstlane((tn * Hs * Ws * cs + cbase) * 2);
+        t_ybs = __builtin_amdgcn_readfirstlane(ty0 - x.padT);
+        const int y_first = t_ybs + (full ? 0 : lw);
+        t_so = rbase + (up ? y_first >> 1 : y_first) * rstride;
+        t_incA = up ? ((y_first & 1) ? rstride : 0) : rstride;            // after this wave's 1st, 3rd, .. row
+        t_incB = up ? ((y_first & 1) ? 0 : rstride) : rstride;            // after its 2nd, 4th, .. row
+        if (!full) { t_incA = up ? rstride : 2 * rstride; t_incB = t_incA; }    // (rows lw, lw + 2, ..)
+        t_tb = __builtin_amdgcn_readfirstlane(tlds0 + tbi * CD_TBYTES + (full ? lw * (44 * 16) : lw * 576));
+        rs_t = __builtin_amdgcn_make_buffer_rsrc(from0 ? a.src0.p : (a.src1.p ? a.src1.p : a.src0.p), 0, live ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
+        // byte offset of this lane's 16 bytes inside a source row, for an even / odd halo row, or out of range
+        const int rp = full ? lane + 44 * lw : lane;
+        const int hp = rp / 6;
+        const int hx = full ? hp : rp >> 1;
+        const int cc = full ? rp - hp * 6 : rp & 1;
+        const int xx = tx0 - x.padL + hx;
+        const bool ok = (unsigned)xx < (unsigned)a.W;
+        const int xs = up ? xx >> 1 : xx;
+        rlE = ok ? (xs * cs + cc * 8) * 2 : (int)0x80000000;
+        rlO = ok ? (xs * cs + (cc ^ 1) * 8) * 2 : (int)0x80000000;
     };
-    auto issue_rows = [&](bool rc_from0, int rc_rbase, int rc_rstride, int rc_ybs, int rc_ush, unsigned rc_dst, bool full, int rlE, int rlO, int u0, int nu) __attribute__((always_inline)) {
+    // row item: halo row HY (48-channel chunk; compile-time) / this wave's U-th row (16-channel chunk: halo row lw + 2 U)
+    auto trow = [&](auto FULLc, auto HYc) __attribute__((always_inline)) {
+        constexpr bool full = decltype(FULLc)::value != 0;
+        constexpr int hy = decltype(HYc)::value;
         if (CD_ABL(x, 4)) return;
-        const bool act = full ? lane < 54 : lane < 36;
-#pragma unroll
-        for (int uu = 0; uu < 18; ++uu) {
-            if (uu >= nu) break;               // (nu is a constant at every call site: the loop unrolls to nu items)
-            const int r = lw + 2 * (u0 + uu);
-            const int hy = full ? r >> 1 : r, half = full ? r & 1 : 0;
-            if (hy >= 18) continue;
-            const int y = rc_ybs + hy;
-            const bool rowok = (unsigned)y < (unsigned)a.H;
-            const int soff = rc_rbase + (y >> rc_ush) * rc_rstride;            // (an out-of-image row fetches nothing: voff is out of range)
-            const int voff = rowok ? ((hy & 1) ? rlO : rlE) : (int)0x80000000;
-            const unsigned ldsrow = rc_dst + hy * (full ? 1728 : 576) + half * 864;
-            if (act) {
-                if (rc_from0) dma16(ldsrow, voff, rs_s0, soff); else dma16(ldsrow, voff, rs_s1, soff);
-            }
+        const int so = t_so;
+        t_so += (hy & 1) ? t_incB : t_incA;
+        if constexpr (full) {
+            int voff = (hy & 1) ? rlO : rlE;
+            if constexpr (hy < 2 || hy >= 16) voff = (unsigned)(t_ybs + hy) < (unsigned)a.H ? voff : (int)0x80000000;
+            dma16i<0>(t_tb + hy * 1728, voff, rs_t, so);
+        } else {
+            int voff = lw ? rlO : rlE;
+            voff = (unsigned)(t_ybs + lw + 2 * hy) < (unsigned)a.H ? voff : (int)0x80000000;
+            if (lane < 36) dma16i<0>(t_tb + hy * 1152, voff, rs_t, so);
         }
     };
 
     // ---- the walk -------------------------------------------------------------------------------------------------------------
     auto tile_of = [&](int item, int k) {
-        const int strip = item / x.segs, seg = item - strip * x.segs;
+        const int strip = item >> x.segs_sh, seg = item & (x.segs - 1);
         CdTile t;
-        t.n = strip / x.tiles_x;
+        t.n = x.tiles_x == 1 ? strip : (int)__umulhi((unsigned)strip, x.tx_magic);
         t.x0 = (strip - t.n * x.tiles_x) * 16;
         t.y0 = (seg * x.tps + k) * 16;
         return t;
@@ -290,8 +319,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     int item = it_first, kt = 0;
     CdTile cur = tile_of(item, 0);
     int tpar = 0, wpar = 0;      // buffers holding the CURRENT chunk's tile / the CURRENT step's weights
-    // bias of this launch's channels lives in the 640-byte pad behind tile buffer 0 (the lanes of the last tile DMA
-    // instruction that would land there are EXEC-masked)
+    // bias of this launch's channels lives in the 640-byte pad behind tile buffer 0 (nothing is fetched there)
     float* const bl = reinterpret_cast<float*>(smem + 18 * 18 * 96);
     if (tid < WROWS) bl[tid] = (a.bias && tid < x.m_cnt) ? a.bias[x.m_base + tid] : 0.f;
     // ... and, behind the bias (96 floats at most), 16 x float4: the LeakyReLU' factors of four channels from their four sign bits (entry n =
@@ -301,14 +329,6 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     if constexpr (SMASK && HAS_MASK) {
         if (tid < 64) reinterpret_cast<float*>(smem + CD_LUT)[tid] = ((tid >> 2) >> (tid & 3)) & 1 ? 1.f : LRELU_SLOPE;
     }
-    if (wload) issue_w(wchunk(0), 0 < x.nfull, 0, 0);
-    else {
-        bool q_rs; int q_rbase, q_rstride, q_ybs, q_ush; unsigned q_dst;
-        row_ctx(cur, 0, 0, q_rs, q_rbase, q_rstride, q_ybs, q_ush, q_dst);
-        issue_rows(q_rs, q_rbase, q_rstride, q_ybs, q_ush, q_dst, 0 < x.nfull, row_lane(cur, 0, 0), row_lane(cur, 0, 1), 0, 18);
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
 
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(UROT ? a.urot.p : a.dst.p, 0, CD_ABL(x, 64) ? 0 : (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_sgn = __builtin_amdgcn_make_buffer_rsrc(SOUT ? a.sign_out : a.urot_smask, 0, (!CD_ABL(x, 64) && (SOUT || (UROT && a.urot_smask))) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
@@ -326,6 +346,24 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         u_pc[k] = p < 8 * cpp ? (j | (c << 8)) : -1;
     }
 
+    // The whole walk exists once per loader ROLE (waves 0-1 / waves 2-3): no wave-uniform role branch inside it, and the register allocator
+    // sees two independent paths (one shared K loop with role branches around the MFMAs made it keep the accumulators in different
+    // registers per arm and spill what lives across them).
+    auto run = [&](auto WLc) __attribute__((always_inline)) {
+    constexpr bool WL = decltype(WLc)::value != 0;
+    if constexpr (WL) wslice(0 < x.nfull, wlds0, wchunk(0));
+    else {
+        tile_setup(cur.n, cur.y0, cur.x0, 0, 0, true);
+        if (0 < x.nfull) cd_static_for<18>([&](auto hc) { trow(cd_ic<1>{}, hc); });
+        else cd_static_for<9>([&](auto hc) { trow(cd_ic<0>{}, hc); });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    // The two workgroups of a CU start together and, with equal work, stay in phase: both sit in their epilogue (stores, no MFMAs) and in
+    // the waits at a chunk's end at the same time.  Starting the one in the CU's second workgroup slot (HW_ID.TG_ID) a few microseconds late
+    // puts one's latency phases under the other's MFMAs; the price is that delay at the end of the launch.
+    if (x.dephase > 0 && ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 16) & 1))
+        for (int d = 0; d < x.dephase; ++d) __builtin_amdgcn_s_sleep(16);
     stamp();
     for (;;) {
         // next tile of this workgroup (same item one tile down, or the top of its next item)
@@ -336,11 +374,13 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
 
         // accumulators start at the bias: row = 32 mt + 8 (r >> 2) + 4 kh + (r & 3)
         f32x16 acc[MT][2];
+        int bo = kh * 16;
+        asm volatile("" : "+v"(bo));      // (opaque: otherwise the 96 initial values are loop invariants -- a second register set kept live for the whole launch)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const f32x4 bb = *reinterpret_cast<const f32x4*>(bl + mt * 32 + g * 8 + kh * 4);
+                const f32x4 bb = *reinterpret_cast<const f32x4*>(smem + 18 * 18 * 96 + (mt * 32 + g * 8) * 4 + bo);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { acc[mt][0][g * 4 + j] = bb[j]; acc[mt][1][g * 4 + j] = bb[j]; }
             }
@@ -349,80 +389,121 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             const bool last_chunk = c + 1 == nch;
             const bool pf = !last_chunk || has_next;           // is there a chunk to prefetch while this one computes
             const int pc = last_chunk ? 0 : c + 1;
-            CdTile pt;                                           // (by value: a reference picked at run time would put both tiles in scratch)
-            pt.n = last_chunk ? nxt.n : cur.n; pt.y0 = last_chunk ? nxt.y0 : cur.y0; pt.x0 = last_chunk ? nxt.x0 : cur.x0;
-            const bool pf_full = pc < x.nfull;
-            int rlE = 0, rlO = 0;
-            if (!wload && pf) { rlE = row_lane(pt, pc, 0); rlO = row_lane(pt, pc, 1); }
-            bool rc_rs; int rc_rbase, rc_rstride, rc_ybs, rc_ush; unsigned rc_dst;      // (unconditional: scalar values defined on one
-            row_ctx(pt, pc, tpar ^ 1, rc_rs, rc_rbase, rc_rstride, rc_ybs, rc_ush, rc_dst);  //  path only end up in VGPRs)
-            const int wcb_c = wchunk(c), wcb_p = wchunk(pc);
-            const bool cfull = c < x.nfull;
-            // step head: the loaders start the fetches that must have landed one step (weights) / one chunk (tile) from now
-            auto step_head = [&](int t) __attribute__((always_inline)) {
-                if (wload) {
-                    if (t < 8) issue_w(wcb_c, cfull, t + 1, wpar ^ 1);
-                    else if (pf) issue_w(wcb_p, pf_full, 0, wpar ^ 1);
-                } else if (pf && t < 8) {
-                    if (pf_full) issue_rows(rc_rs, rc_rbase, rc_rstride, rc_ybs, rc_ush, rc_dst, true, rlE, rlO, t < 2 ? 3 * t : 2 * t + 2, t < 2 ? 3 : 2);   // 18 row items per wave over steps 0..7
-                    else issue_rows(rc_rs, rc_rbase, rc_rstride, rc_ybs, rc_ush, rc_dst, false, rlE, rlO, t < 1 ? 0 : t + 1, t < 1 ? 2 : 1);            // 9 row items per wave
-                }
-            };
-            // step tail: own DMA landed, then ONE barrier: every wave's DMA landed and every wave is done with this step's buffers
-            auto step_tail = [&](int t) __attribute__((always_inline)) {
-                if ((wload || t == 8) && !CD_ABL(x, 16)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (!CD_ABL(x, 32)) __builtin_amdgcn_s_barrier();
-                wpar ^= 1;
-            };
-            if (c < x.nfull) {
-                const unsigned bE = tlds0 + tpar * CD_TBYTES + bE48, bO = tlds0 + tpar * CD_TBYTES + bO48;
-#define CD_STEP48(T, I, J)                                                  \
-    {                                                                       \
-        const unsigned ap = wlds0 + wpar * WBYTES + aB48, bp = (I & 1) ? bO : bE; \
-        half8 aq0[MT], bq0[2], aq1[MT], bq1[2];                             \
-        cd_reads<MT, 3, I, J, 0>(aq0, bq0, ap, bp);                         \
-        step_head(T);                 /* the loaders' DMA issue covers the latency of the first fragment reads */ \
-        lds_wait0<MT>(aq0, bq0);                                            \
-        cd_reads<MT, 3, I, J, 1>(aq1, bq1, ap, bp);                         \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        lds_wait0<MT>(aq1, bq1);                                            \
-        cd_reads<MT, 3, I, J, 2>(aq0, bq0, ap, bp);                         \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, aq1, bq1);                \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        lds_wait0<MT>(aq0, bq0);                                            \
-        if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, aq0, bq0);                \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        step_tail(T);                                                       \
-    }
-                CD_STEP48(0, 0, 0) CD_STEP48(1, 0, 1) CD_STEP48(2, 0, 2)
-                CD_STEP48(3, 1, 0) CD_STEP48(4, 1, 1) CD_STEP48(5, 1, 2)
-                CD_STEP48(6, 2, 0) CD_STEP48(7, 2, 1) CD_STEP48(8, 2, 2)
-#undef CD_STEP48
-            } else {
-                const unsigned bE = tlds0 + tpar * CD_TBYTES + bE16, bO = tlds0 + tpar * CD_TBYTES + bO16;
-#define CD_STEP16(T, I, J)                                                  \
-    {                                                                       \
-        const unsigned ap = wlds0 + wpar * WBYTES + aB16, bp = (I & 1) ? bO : bE; \
-        half8 aq0[MT], bq0[2];                                              \
-        cd_reads<MT, 1, I, J, 0>(aq0, bq0, ap, bp);                         \
-        step_head(T);                                                       \
-        lds_wait0<MT>(aq0, bq0);                                            \
-        cd_mmas<MT, BF>(acc, aq0, bq0);                                     \
-        __builtin_amdgcn_sched_barrier(0);                                  \
-        step_tail(T);                                                       \
-    }
-                CD_STEP16(0, 0, 0) CD_STEP16(1, 0, 1) CD_STEP16(2, 0, 2)
-                CD_STEP16(3, 1, 0) CD_STEP16(4, 1, 1) CD_STEP16(5, 1, 2)
-                CD_STEP16(6, 2, 0) CD_STEP16(7, 2, 1) CD_STEP16(8, 2, 2)
-#undef CD_STEP16
+            const bool cfull = c < x.nfull, pf_full = pc < x.nfull;
+            // fragment addresses of this chunk: tile buffer tpar; weight buffer wpar in the even steps, the other one in the odd steps
+            const unsigned tb = tlds0 + tpar * CD_TBYTES;
+            int bE_ = bE48, aB_ = aB48;
+            if (!cfull) {
+                int lo = lane;
+                asm volatile("" : "+v"(lo));          // (opaque: derived here, not hoisted out of the tile loop into live registers)
+                const int l31o = lo & 31, kho = lo >> 5;
+                bE_ = (4 * w + (l31o >> 4)) * 576 + (l31o & 15) * 32 + ((kho ^ ((l31o >> 4) & 1)) << 4);
+                aB_ = l31o * 32 + ((kho ^ ((l31o >> 3) & 1)) << 4);
             }
-            tpar ^= 1;
+            const unsigned bE = tb + bE_, bO = tb + (bE_ ^ 16);
+            const unsigned apE = wlds0 + wpar * WBYTES + aB_, apO = wlds0 + (wpar ^ 1) * WBYTES + aB_;
+            // loader state of this chunk.  weights: the slice of tap t+1 goes to the buffer step t does NOT read; wso = its byte offset
+            // (this wave's first piece), advanced by one tap per step.  tiles: the rows of the next chunk / the next tile's first chunk.
+            int wso = 0;
+            unsigned wdA = 0, wdB = 0;
+            if constexpr (WL) {
+                const int wb = wbase(cfull);
+                wso = wchunk(c) + wb;
+                wdA = __builtin_amdgcn_readfirstlane(wlds0 + wpar * WBYTES + wb);
+                wdB = __builtin_amdgcn_readfirstlane(wlds0 + (wpar ^ 1) * WBYTES + wb);
+            } else {
+                tile_setup(last_chunk ? nxt.n : cur.n, last_chunk ? nxt.y0 : cur.y0, last_chunk ? nxt.x0 : cur.x0, pc, tpar ^ 1, pf);
+            }
+            // ONE role-specialised body per (role, kind of this chunk, kind of the prefetched chunk): no wave-uniform branch inside a step.
+            // A step = one tap: KS K-steps of 2 MT MFMAs; the loader pieces of the step sit in the gaps BEHIND the MFMAs of its first
+            // K-step (an MFMA occupies the matrix core for 8 issue slots; what the wave issues meanwhile is free), K-step k+1's fragment
+            // reads are issued before K-step k's MFMAs; one s_barrier per step.
+            auto body = [&](auto FULLc, auto PFULLc) __attribute__((always_inline)) {
+                constexpr bool FULL = decltype(FULLc)::value != 0, PFULL = decltype(PFULLc)::value != 0;
+                constexpr int KS = FULL ? 3 : 1;
+                constexpr bool MV = MOVE && FULL;
+                half8 fa[2][MT], fb[2][2];
+                auto gap = [&](auto Tc, auto Ic) __attribute__((always_inline)) {
+                    constexpr int T = decltype(Tc)::value, i = decltype(Ic)::value;
+                    if constexpr (WL) {
+                        using S = CdWSplit<MT, FULL>;
+                        constexpr int NP = S::NB + (S::extra ? 1 : 0);
+                        if constexpr (T < 8) {
+                            if constexpr (i == 0) wso += wts;
+                            cd_static_for<NP>([&](auto jc) {
+                                constexpr int j = decltype(jc)::value;
+                                if constexpr ((j < G - 1 ? j : G - 1) == i) wpiece(FULLc, jc, (T & 1) ? wdA : wdB, wso);
+                            });
+                        } else if constexpr (i == 0) {
+                            if (pf) wslice(pf_full, wlds0 + (wpar ^ 1) * WBYTES, wchunk(pc));
+                        }
+                    } else {
+                        // the rows of the prefetched chunk, EARLY: one item per gap from step 0 on (MT = 3: 18 items in steps 0-2), so that
+                        // the last of them has six steps to land before the chunk's last barrier waits for it (with 3 / 2 items per step
+                        // up to step 7 that wait was ~1.9 us per chunk: rows from HBM need more than one step)
+                        constexpr int N = PFULL ? 18 : 9, NS = G >= 3 ? G : 3;
+                        constexpr int k0 = T * NS, n = k0 >= N ? 0 : (N - k0 < NS ? N - k0 : NS);
+                        cd_static_for<n>([&](auto kc) {
+                            constexpr int k = decltype(kc)::value;
+                            if constexpr ((k < G - 1 ? k : G - 1) == i) trow(PFULLc, cd_ic<k0 + k>{});
+                        });
+                    }
+                };
+                auto sync = [&](auto Tc) __attribute__((always_inline)) {
+                    constexpr int T = decltype(Tc)::value;
+                    if (WL || T == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                };
+                auto step = [&](auto Tc) __attribute__((always_inline)) {
+                    constexpr int T = decltype(Tc)::value, I = T / 3, J = T % 3;
+                    constexpr int P = MV ? (T & 1) : 0;          // fragment set that holds K-step 0
+                    const unsigned ap = (T & 1) ? apO : apE, bp = (I & 1) ? bO : bE;
+                    if constexpr (!MV || T == 0) cd_reads<MT, KS, I, J, 0>(fa[P], fb[P], ap, bp);
+                    lds_wait0<MT>(fa[P], fb[P]);
+                    if constexpr (KS > 1) cd_reads<MT, KS, I, J, 1>(fa[P ^ 1], fb[P ^ 1], ap, bp);
+                    __builtin_amdgcn_sched_barrier(0);
+                    cd_static_for<G>([&](auto ic) {
+                        constexpr int i = decltype(ic)::value;
+                        if (!CD_ABL(x, 1)) cd_mma<BF>(acc[i >> 1][i & 1], fa[P][i >> 1], fb[P][i & 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        gap(Tc, ic);
+                        __builtin_amdgcn_sched_barrier(0);
+                    });
+                    if constexpr (KS > 1) {
+                        lds_wait0<MT>(fa[P ^ 1], fb[P ^ 1]);
+                        cd_reads<MT, KS, I, J, 2>(fa[P], fb[P], ap, bp);
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, fa[P ^ 1], fb[P ^ 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        lds_wait0<MT>(fa[P], fb[P]);
+                        if constexpr (MV && T < 8) {
+                            // the barrier in FRONT of the last K-step's MFMAs: every fragment of this step has been read; the next step's
+                            // first fragments travel while these MFMAs run
+                            sync(Tc);
+                            constexpr int T1 = T + 1, I1 = T1 / 3, J1 = T1 % 3;
+                            cd_reads<MT, KS, I1, J1, 0>(fa[P ^ 1], fb[P ^ 1], (T1 & 1) ? apO : apE, (I1 & 1) ? bO : bE);
+                            __builtin_amdgcn_sched_barrier(0);
+                            if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, fa[P], fb[P]);
+                            __builtin_amdgcn_sched_barrier(0);
+                        } else {
+                            if (!CD_ABL(x, 1)) cd_mmas<MT, BF>(acc, fa[P], fb[P]);
+                            __builtin_amdgcn_sched_barrier(0);
+                            sync(Tc);
+                        }
+                    } else sync(Tc);
+                };
+                cd_static_for<9>(step);
+            };
+            if constexpr (WL) {
+                if (cfull) body(cd_ic<1>{}, cd_ic<1>{}); else body(cd_ic<0>{}, cd_ic<1>{});
+            } else if (cfull) {
+                if (pf_full) body(cd_ic<1>{}, cd_ic<1>{}); else body(cd_ic<1>{}, cd_ic<0>{});
+            } else {
+                if (pf_full) body(cd_ic<0>{}, cd_ic<1>{}); else body(cd_ic<0>{}, cd_ic<0>{});
+            }
+            tpar ^= 1; wpar ^= 1;
             stamp();
         }
-
         // ---- epilogue, direct form (round 5; every variant but the fused UPSUM_BWD, whose 2x2 sums need the transposed tile): after the
         // permlane swap lane (pixel l31, kh) holds the whole 16-byte piece mt*4 + 2gp + kh of its pixel -- it stores it straight from
         // registers (32-byte runs at a 192-byte pitch; the L2 merges the four pieces of a 64-byte sector, they arrive within a few hundred
@@ -432,6 +513,12 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         // forward role, ~990 -> ~530 in the data-gradient role (no LeakyReLU there: compile-time), measured in tools/ab_libs.sh.
         if (!CD_ABL(x, 8) && !HAS_UPS && (cpp & 1) == 0) {
             const int pix_t = (cur.n * a.H + cur.y0 + 4 * w) * a.W + cur.x0;     // first pixel of this wave's 4 rows
+            // pieces come in pairs (2i, 2i+1); their count as a SCALAR integer: compared against the loop index it is s_cmp + s_cbranch_scc (as
+            // `i * 2 >= cpp` the allocator kept the comparison as a spilled lane mask and re-made it through v_cndmask / v_cmp per piece)
+            const int npair = __builtin_amdgcn_readfirstlane(cpp >> 1);
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));      // (opaque: the epilogue's per-lane offsets are derived per tile, not kept live through the K loop)
+            const int l31 = lane_o & 31, kh = lane_o >> 5;
             const int lrow = l31 >> 4, lcol = l31 & 15;
             const int lpix = lrow * a.W + lcol;
             int ur_base = 0, ur_iu = 0, ur_iv = 0, ur_ju = 0, ur_jv = 0;
@@ -465,7 +552,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                 u32x4_t ab[MT * 2], mb[MT * 2];
 #pragma unroll
                 for (int i = 0; i < MT * 2; ++i) {
-                    if (i * 2 >= cpp) break;
+                    if (i >= npair) break;
                     if constexpr (HAS_ADD)
                         ab[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, lpix * a.add.cs * 2 + kh * 16 + i * 32,
                                                                       __builtin_amdgcn_readfirstlane((pix_p * a.add.cs + a.add.co + x.m_base) * 2), 0);
@@ -481,7 +568,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                     for (int gp = 0; gp < 2; ++gp) {
                         constexpr int DUMMY = 0; (void)DUMMY;
                         const int i = mt * 2 + gp;
-                        if (i * 2 >= cpp) break;                  // (cpp is even here: the pieces 2i, 2i+1 exist together)
+                        if (i >= npair) break;                    // (cpp is even here: the pieces 2i, 2i+1 exist together)
                         unsigned pk[2][2];
 #pragma unroll
                         for (int h = 0; h < 2; ++h) {
@@ -539,6 +626,10 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                             }
                         }
                         __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, d_lane + i * 32, d_so, 0);
+                        // A 16-byte store reads its data registers some cycles after it issued -- more than the two wait states the
+                        // compiler pads when the memory pipeline is backed up (here: behind the LDS-DMA streams and 11 other stores): a
+                        // VALU write to `o` five instructions later reached HBM in ~1e-5 of the pieces (round 6, tools/r6_ab3.sh).
+                        asm volatile("s_nop 7" ::: "memory");
                         if constexpr (UROT || SOUT) {
                             if (SOUT || a.urot_smask) {
                                 // sign byte of the piece: bit 2q = (low half of dword q > 0), bit 2q+1 = (high half > 0), on the raw 16-bit
@@ -567,6 +658,23 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         if (!CD_ABL(x, 8)) {
             char* reg = tbuf0 + (tpar ^ 1) * CD_TBYTES + w * (32 * OSTR);
             const int pix_t = (cur.n * a.H + cur.y0 + 4 * w) * a.W + cur.x0;     // first pixel of this wave's 4 rows
+            int lane_o = lane;
+            asm volatile("" : "+v"(lane_o));
+            const int l31 = lane_o & 31, kh = lane_o >> 5;
+            // row instruction k covers 16-byte pieces [64k, 64k+64) of this wave's 32-pixel pass; piece p = (pixel p / cpp, piece p % cpp);
+            // pixel px = (row px >> 4 of the pass, column px & 15)
+            int e_pc[NEK];     // pixel | piece << 8, or -1
+            if constexpr (!HAS_UPS) {
+#pragma unroll
+                for (int k = 0; k < NEK; ++k) {
+                    const int p = k * 64 + lane_o;
+                    const int px = p / cpp, c = p - px * cpp;
+                    e_pc[k] = p < 32 * cpp ? (px | (c << 8)) : -1;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NEK; ++k) e_pc[k] = -1;
+            }
             // fused UNROT_FWD: image n = r*B + b; the pixel (y, x) is S_r[u, v] with (u, v) = (y + 1, x) and lands at (b, i, j),
             //   r=0: (i,j) = (u,v); r=1: (v, P-1-u); r=2: (P-1-u, P-1-v); r=3: (P-1-v, u)    -- as affine forms with uniform coefficients
             int ur_base = 0, ur_iu = 0, ur_iv = 0, ur_ju = 0, ur_jv = 0;
@@ -727,12 +835,16 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         }
         stamp();
         if (!has_next) break;
-        // the dead buffer becomes the target of the next tile fetches (issued from step 0 on): every wave must be done with it
-        __builtin_amdgcn_s_barrier();
+        // LDS form of the epilogue: the dead buffer becomes the target of the next tile fetches (issued from step 0 on): every wave must be done
+        // with it.  (The direct form touches no tile buffer: the barrier of the tile's last step is enough.)
+        if (CD_EXP_BARRIER || HAS_UPS || (cpp & 1)) __builtin_amdgcn_s_barrier();
         item = nitem; kt = nkt; cur = nxt;
     }
+    };
+    if (wload) run(cd_ic<1>{}); else run(cd_ic<0>{});
 }
 
+#ifndef CD_KERNEL_ONLY      // (tuning aid: a translation unit that includes this file to compile single instantiations)
 // ---- host side ----------------------------------------------------------------------------------------------------------------
 // halo window of a 3x3 tap set; returns false if the taps are not a full 3x3 window in forward or mirrored order
 static bool cd_window(const ssdn_conv_args* a, int* padT, int* padL, int* rev) {
@@ -805,6 +917,9 @@ static int cd_launch(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
     x.segs = 1;
     while (nstrips * x.segs < 2 * cus && x.segs < x.tiles_y && x.tiles_y % (x.segs * 2) == 0) x.segs *= 2;
     x.tps = x.tiles_y / x.segs;
+    x.segs_sh = 0;
+    while ((1 << x.segs_sh) < x.segs) ++x.segs_sh;
+    x.tx_magic = x.tiles_x > 1 ? (unsigned)((0x100000000ull + x.tiles_x - 1) / x.tiles_x) : 0u;
     x.nitems = nstrips * x.segs;
     const int grid = x.nitems < 2 * cus ? x.nitems : 2 * cus;
     x.xcd_map = (x.nitems % 8 == 0 && grid % 8 == 0) ? 1 : 0;
@@ -855,12 +970,14 @@ int launch_conv_dma(const ssdn_conv_args* a, hipStream_t s) {
     CdAux x;
     if (!cd_window(a, &x.padT, &x.padL, &x.rev)) return ssdn_set_error("conv_dma: not a 3x3 window");
     x.tiles_x = a->W >> 4; x.tiles_y = a->H >> 4;
-    x.segs = 1; x.tps = x.tiles_y; x.nitems = 0; x.xcd_map = 0;
+    x.segs = 1; x.tps = x.tiles_y; x.nitems = 0; x.xcd_map = 0; x.segs_sh = 0; x.tx_magic = 0;
     x.nfull = a->Ktot / 48; x.tail16 = (a->Ktot % 48) ? 1 : 0;
     static const int env_ablate = [] { const char* e = ssdn_tuning_env("SSDN_CDMA_ABLATE"); return e ? atoi(e) : 0; }();
     x.ablate = env_ablate;
     static const int env_wrep = [] { const char* e = ssdn_tuning_env("SSDN_CDMA_WREP"); return e ? atoi(e) : 0; }();
     x.wrep = env_wrep;
+    static const int env_dephase = [] { const char* e = ssdn_tuning_env("SSDN_CDMA_DEPHASE"); return e ? atoi(e) : CD_DEPHASE; }();
+    x.dephase = env_dephase;
     x.trace = (unsigned long long*)ssdn_debug_get_trace();
     int rc = 0;
     for (int mb = 0; mb < a->Mpad && !rc; mb += 96) {
@@ -878,3 +995,5 @@ int launch_conv_dma(const ssdn_conv_args* a, hipStream_t s) {
     SSDN_CHECK_HIP(hipGetLastError());
     return 0;
 }
+
+#endif

@@ -116,7 +116,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_conv_thin(ssdn_conv_args a, int 
     constexpr int OSTR = MT * 64 + 16;
     char* reg = smem + (((HH * HW + 1) * 8 + 15) & ~15) + wave * (32 * OSTR);
     const int npc = a.M >> 3;
-    const unsigned npc_magic = (unsigned)((0x100000000ull + npc - 1) / npc);
+    const unsigned npc_magic = npc <= 1 ? 0u : (unsigned)((0x100000000ull + npc - 1) / npc);      // (npc == 1: 2^32 does not fit -- the quotient is e)
     h16* dst = (h16*)a.dst.p + a.dst.co;
     const int zoff = HH * HW * 8;
 #pragma unroll 2
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(CT_THREADS) void k_conv_thin(ssdn_conv_args a, int 
         __builtin_amdgcn_wave_barrier();
         const long long pix0 = (long long)(n * a.H + y0 + (((wave * 8 + i) * 32) >> 6)) * a.W + x0 + (((wave * 8 + i) * 32) & 63);
         for (int e = lane; e < 32 * npc; e += 64) {
-            const int p = (int)__umulhi((unsigned)e, npc_magic), cc = e - p * npc;      // e / npc (exact for e < 2^16: magic = ceil(2^32 / npc))
+            const int p = npc_magic ? (int)__umulhi((unsigned)e, npc_magic) : e, cc = e - p * npc;      // e / npc (exact for e < 2^16: magic = ceil(2^32 / npc))
             const u32x4_t o = *reinterpret_cast<const u32x4_t*>(reg + (i & 1) * (4 * 32 * OSTR) + p * OSTR + cc * 16);
             *reinterpret_cast<u32x4_t*>(dst + (pix0 + p) * a.dst.cs + cc * 8) = o;
             if (a.sign_out) {      // LeakyReLU sign byte of the piece (ssdn_conv_args.sign_out): bit q = (channel q > 0), on the raw fp16 halves
@@ -213,7 +213,7 @@ static bool thin_window(const ssdn_conv_args* a, unsigned long long* tapmap, int
 bool conv_thin_eligible(const ssdn_conv_args* a) {
     if (a->bf16 || a->ntaps != 9 || a->c1 || a->up0 || a->Ktot != 16 || a->c0 != 16 || a->kreal < 1 || a->kreal > 3) return false;
     if (!a->dst.p || a->dst32 || !a->act || !a->bias || a->pool.p || a->mask.p || a->add.p || a->upsum.p || a->unrot.p) return false;
-    if ((a->H & 15) || (a->W & 63) || (a->M & 7) || a->Mpad > 64 || a->Mpad < 32) return false;
+    if ((a->H & 15) || (a->W & 63) || a->M < 8 || (a->M & 7) || a->Mpad > 64 || a->Mpad < 32) return false;
     if (a->src0.cs < 4 || (a->src0.cs & 3) || (a->src0.co & 3)) return false;      // 8-byte pixel heads
     unsigned long long map; int dy0;
     int pt, pb, pl, pr;

@@ -51,7 +51,9 @@ int ssdn_plan_load(const void* blob, int64_t nbytes, ssdn_plan** out) {
         t.bytes = r.get<uint64_t>();
         t.alias = r.get<int32_t>();
         (void)r.get<int32_t>();
-        if (t.alias >= 0) { if ((uint32_t)t.alias >= k) r.bad = true; else t.off = P->t[t.alias].off; }
+        if (t.alias >= 0) {      // a view of an earlier tensor: never larger than what it views (a relocation is bounded by the alias's own size)
+            if ((uint32_t)t.alias >= k || t.bytes > P->t[t.alias].bytes) r.bad = true; else t.off = P->t[t.alias].off;
+        }
         else { t.off = off; off += (t.bytes + 255) & ~255ull; }
         P->t.push_back(t);
     }
@@ -70,7 +72,7 @@ int ssdn_plan_load(const void* blob, int64_t nbytes, ssdn_plan** out) {
             for (uint32_t j = 0; j < nr && !r.bad; ++j) {
                 PlanReloc q;
                 q.off = r.get<uint32_t>(); q.tensor = r.get<uint32_t>(); q.delta = r.get<uint64_t>();
-                if (q.off + 8 > ab || q.tensor >= nt || q.delta > P->t[q.tensor].bytes) r.bad = true;
+                if ((uint64_t)q.off + 8 > ab || q.tensor >= nt || q.delta > P->t[q.tensor].bytes) r.bad = true;      // (64-bit: q.off + 8 must not wrap)
                 op.rel.push_back(q);
             }
             P->ops[ph].push_back(std::move(op));

@@ -88,7 +88,8 @@ class GradExchange:
     """Bucketed gradient all-reduce overlapped with the backward pass.
 
         ex = GradExchange(world, bucket_ranges(...))
-        ... backward op list enqueued (it records ex.event_handles()[k] when bucket k is complete) ...
+        ... backward op list enqueued (its SSDN_OP_EVENT_RECORD ops record the marks made with ex.new_event(buckets): one per
+            (point of the list, lane) behind which a bucket's last slab reduction on that lane has been enqueued) ...
         ex.launch(flat_grad)        # one asynchronous all-reduce per bucket, each behind its bucket's event
         scale = ex.finish()         # the current stream waits for the collectives; returns 1 / world for Adam
 

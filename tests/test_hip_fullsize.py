@@ -12,6 +12,7 @@ statically scheduled weight-gradient path; 128x128 tiles).  Checks are the size-
 """
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -19,6 +20,7 @@ import restate as R
 from test_hip_denoiser import make_denoiser, _flat_grad_of
 
 pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
 def _inputs(B, C, P, style, seed):
@@ -350,6 +352,19 @@ def test_eval_sizes_forward_vs_oracle(P):
     assert float((o - r["out"]).norm() / r["out"].norm()) <= 5e-3
     for b in range(B):
         assert abs(float(R.psnr(o[b:b + 1], clean[b:b + 1]) - R.psnr(r["out"][b:b + 1], clean[b:b + 1]))) <= 0.05
+    if P == 512:
+        # ... and against the LIVE reference: tests/golden/g_eval_512.npz holds what the reference's own Denoiser (eval mode) returns for the
+        # first image of this batch (oracle/gen_golden_eval.py): strided probe of the denoised image and of mu, the PSNR, the output's norm.
+        # Same bounds as against the oracle: 5e-3 relative on the probe, 0.05 dB.
+        g = np.load(os.path.join(GOLDEN, "g_eval_512.npz"))
+        probe = o[:1, :, 3::16, 5::16].double()
+        want = torch.from_numpy(g["out_probe"]).double()
+        assert float((probe - want).norm() / want.norm()) <= 5e-3
+        mu = out[PipelineOutput.IMG_MU].cpu()[:1, :, 3::16, 5::16].double()
+        wmu = torch.from_numpy(g["mu_probe"]).double()
+        assert float((mu - wmu).norm() / wmu.norm()) <= 5e-3
+        assert abs(float(R.psnr(o[:1], clean[:1])) - float(g["psnr_out"][0])) <= 0.05
+        assert abs(float(o[:1].double().norm()) / float(g["out_norm"]) - 1.0) <= 5e-3
 
 
 def test_full_size_config2_properties():
