@@ -13,7 +13,18 @@ READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
 def main():
-    obj, prefixes = sys.argv[1], sys.argv[2:]
+    # optional: --sgpr-budget N (spilled SGPRs: v_readlane / v_writelane on the VALU port the MFMAs issue from), --only REGEX (mangled names)
+    args = sys.argv[1:]
+    budget, only = None, None
+    while args and args[0].startswith("--"):
+        if args[0] == "--sgpr-budget":
+            budget = int(args[1])
+        elif args[0] == "--only":
+            only = re.compile(args[1])
+        else:
+            sys.exit("check_scratch: unknown option " + args[0])
+        args = args[2:]
+    obj, prefixes = args[0], args[1:]
     with tempfile.TemporaryDirectory() as d:
         tmp = os.path.join(d, os.path.basename(obj))
         os.symlink(os.path.abspath(obj), tmp)
@@ -24,13 +35,16 @@ def main():
     bad, seen = [], 0
     for blk in notes.split("- .agpr_count")[1:]:
         m = re.search(r"\.name:\s+(\S+)", blk)
-        if not m or not any(p in m.group(1) for p in prefixes):
+        if not m or not any(p in m.group(1) for p in prefixes) or (only and not only.search(m.group(1))):
             continue
         seen += 1
         scratch = int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1))
         vspill = int(re.search(r"\.vgpr_spill_count:\s+(\d+)", blk).group(1))
         if scratch or vspill:
             bad.append("%s: %d B of scratch per lane, %d spilled VGPRs" % (m.group(1), scratch, vspill))
+        sspill = int(re.search(r"\.sgpr_spill_count:\s+(\d+)", blk).group(1))
+        if budget is not None and sspill > budget:
+            bad.append("%s: %d spilled SGPRs (budget %d)" % (m.group(1), sspill, budget))
     assert seen, "no kernel matching %s in %s" % (prefixes, obj)
     if bad:
         sys.exit("check_scratch: " + "; ".join(bad))

@@ -51,14 +51,11 @@
 #endif
 
 // A/B aid (EXTRA=-DCD_MOVE_BARRIER=0|1): the step barrier in front of the step's last K-step, the next step's first fragment reads behind it
-#ifndef CD_EXP_BARRIER
-#define CD_EXP_BARRIER 0
-#endif
 #ifndef CD_DEPHASE
 #define CD_DEPHASE 0
 #endif
 #ifndef CD_MOVE_BARRIER
-#define CD_MOVE_BARRIER 0
+#define CD_MOVE_BARRIER 1
 #endif
 
 namespace {
@@ -151,9 +148,9 @@ template <class F, int... Is>
 __device__ __forceinline__ void cd_static_for_impl(F& f, std::integer_sequence<int, Is...>) { (f(cd_ic<Is>{}), ...); }
 template <int N, class F>
 __device__ __forceinline__ void cd_static_for(F&& f) { cd_static_for_impl(f, std::make_integer_sequence<int, N>{}); }
-template <int IMM>
+template <int IMM, int AUX = 0>
 __device__ __forceinline__ void dma16i(unsigned lds_addr, int voff, __amdgpu_buffer_rsrc_t rs, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cd_lds_ptr)(size_t)lds_addr, 16, voff, soff, IMM, 0);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (cd_lds_ptr)(size_t)lds_addr, 16, voff, soff, IMM, AUX);
 }
 
 }  // namespace
@@ -164,8 +161,15 @@ __device__ __forceinline__ void dma16i(unsigned lds_addr, int voff, __amdgpu_buf
 // its un-rotated place in ssdn_conv_args.urot (+ optional LeakyReLU sign bytes) instead of dst; bit 4 (forward role) = the launch also
 // writes the LeakyReLU sign bytes of its output (ssdn_conv_args.sign_out); bit 5 (data-gradient role, with bit 0 or bit 2) = the
 // LeakyReLU' operand arrives as sign bytes (mask_sign / upsum_mask_sign: one byte per 16-byte piece instead of the piece)
-template <int MT, bool BF, int EPI>
+// AF ("all full"): every chunk of the launch has 48 channels (Ktot % 48 == 0) -- the K loop is then ONE role-specialised body.  With the
+// chunk kind as a run-time choice between bodies (AF = false: a 16-channel tail chunk exists) the register allocator keeps the accumulators
+// in different registers per body and copies 96 registers at every chunk boundary (252 registers, SGPR spills); with one body the same
+// kernel takes ~155 registers and no copy (round 6).
+// KIND 2: n >= 1 chunks of 48 channels, then ONE 16-channel chunk (decode_block_1.0: 96 up-sampled + 3 image channels in a 16-channel slot) --
+// the bodies follow each other in program order (full .. full, full with a tail prefetch, tail), again without a run-time choice.
+template <int MT, bool BF, int EPI, int KIND>
 __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
+    constexpr bool AF = KIND == 1;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int WROWS = MT * 32;
     constexpr int WBYTES = WROWS * 96;        // one (tap, 48-channel chunk) weight slice
@@ -227,7 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     const int wvoff = lane * 16;
     const bool lw0 = __builtin_amdgcn_readfirstlane(tid >> 6) == 0;       // (its own scalar compare: not the lane mask `wload` and `lw` share)
     auto wchunk = [&](int c) __attribute__((always_inline)) {
-        return __builtin_amdgcn_readfirstlane((c * 48 * a.Mpad + x.m_base * (c < x.nfull ? 48 : 16)) * 2 + wt0);
+        return __builtin_amdgcn_readfirstlane((c * 48 * a.Mpad + x.m_base * ((AF || c < x.nfull) ? 48 : 16)) * 2 + wt0);
     };
     // piece j of this wave's share of a slice: d / so = LDS address / byte offset of the wave's first piece
     auto wpiece = [&](auto FULLc, auto Jc, unsigned d, int so) __attribute__((always_inline)) {
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     };
     auto wslice = [&](bool full, unsigned dbuf, int sl) __attribute__((always_inline)) {     // a whole slice (start-up, chunk change)
         const int wb = wbase(full);
-        if (full) cd_static_for<CdWSplit<MT, true>::NB + 1>([&](auto jc) { wpiece(cd_ic<1>{}, jc, dbuf + wb, sl + wb); });
+        if (AF || full) cd_static_for<CdWSplit<MT, true>::NB + 1>([&](auto jc) { wpiece(cd_ic<1>{}, jc, dbuf + wb, sl + wb); });
         else cd_static_for<CdWSplit<MT, false>::NB + 1>([&](auto jc) { wpiece(cd_ic<0>{}, jc, dbuf + wb, sl + wb); });
     };
 
@@ -266,10 +270,10 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         const int cs = from0 ? a.src0.cs : a.src1.cs;
         const int cbase = from0 ? a.src0.co + k0 : a.src1.co + k0 - a.c0;
         const int Hs = up ? H0 : a.H, Ws = up ? W0 : a.W;
-        const bool full = c < x.nfull;
+        const bool full = AF || c < x.nfull;
         // (readfirstlane: the values ARE wave-uniform; saying so keeps the row arithmetic on the scalar unit)
         const int rstride = __builtin_amdgcn_readfirstlane(Ws * cs * 2);
-        const int rbase = __builtin_amdgcn_readfirstlane((tn * Hs * Ws * cs + cbase) * 2);
+        const int rbase = __builtin_amdgcn_readfirstlane(((CD_ABL(x, 128) ? 0 : tn) * Hs * Ws * cs + cbase) * 2);
         t_ybs = __builtin_amdgcn_readfirstlane(ty0 - x.padT);
         const int y_first = t_ybs + (full ? 0 : lw);
         t_so = rbase + (up ? y_first >> 1 : y_first) * rstride;
@@ -299,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         if constexpr (full) {
             int voff = (hy & 1) ? rlO : rlE;
             if constexpr (hy < 2 || hy >= 16) voff = (unsigned)(t_ybs + hy) < (unsigned)a.H ? voff : (int)0x80000000;
-            dma16i<0>(t_tb + hy * 1728, voff, rs_t, so);
+            if (CD_ABL(x, 512)) dma16i<0, 2>(t_tb + hy * 1728, voff, rs_t, so);
+            else dma16i<0>(t_tb + hy * 1728, voff, rs_t, so);
         } else {
             int voff = lw ? rlO : rlE;
             voff = (unsigned)(t_ybs + lw + 2 * hy) < (unsigned)a.H ? voff : (int)0x80000000;
@@ -351,10 +356,12 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // registers per arm and spill what lives across them).
     auto run = [&](auto WLc) __attribute__((always_inline)) {
     constexpr bool WL = decltype(WLc)::value != 0;
-    if constexpr (WL) wslice(0 < x.nfull, wlds0, wchunk(0));
-    else {
+    if constexpr (WL) {
+        wslice(KIND != 0 || 0 < x.nfull, wlds0, wchunk(0));
+        wslice(KIND != 0 || 0 < x.nfull, wlds0 + WBYTES, wchunk(0) + wts);       // tap 1: see "first step of a tile" below
+    } else {
         tile_setup(cur.n, cur.y0, cur.x0, 0, 0, true);
-        if (0 < x.nfull) cd_static_for<18>([&](auto hc) { trow(cd_ic<1>{}, hc); });
+        if (KIND != 0 || 0 < x.nfull) cd_static_for<18>([&](auto hc) { trow(cd_ic<1>{}, hc); });
         else cd_static_for<9>([&](auto hc) { trow(cd_ic<0>{}, hc); });
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -362,6 +369,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     // The two workgroups of a CU start together and, with equal work, stay in phase: both sit in their epilogue (stores, no MFMAs) and in
     // the waits at a chunk's end at the same time.  Starting the one in the CU's second workgroup slot (HW_ID.TG_ID) a few microseconds late
     // puts one's latency phases under the other's MFMAs; the price is that delay at the end of the launch.
+    if (CD_TUNING && x.trace && tid == 0) x.trace[(size_t)blockIdx.x * 32 + 31] = 0x100000000ull | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
     if (x.dephase > 0 && ((__builtin_amdgcn_s_getreg((31 << 11) | 4) >> 16) & 1))
         for (int d = 0; d < x.dephase; ++d) __builtin_amdgcn_s_sleep(16);
     stamp();
@@ -385,11 +393,13 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                 for (int j = 0; j < 4; ++j) { acc[mt][0][g * 4 + j] = bb[j]; acc[mt][1][g * 4 + j] = bb[j]; }
             }
 
-        for (int c = 0; c < nch; ++c) {
+        // one chunk; CFc / PFc: kind of this chunk / of the prefetched one -- 1 = 48 channels, 0 = 16 channels, 2 = decided at run time
+        auto chunk = [&](int c, auto CFc, auto PFc) __attribute__((always_inline)) {
+            constexpr int CF = decltype(CFc)::value, PFK = decltype(PFc)::value;
             const bool last_chunk = c + 1 == nch;
             const bool pf = !last_chunk || has_next;           // is there a chunk to prefetch while this one computes
             const int pc = last_chunk ? 0 : c + 1;
-            const bool cfull = c < x.nfull, pf_full = pc < x.nfull;
+            const bool cfull = CF == 2 ? c < x.nfull : CF == 1, pf_full = PFK == 2 ? pc < x.nfull : PFK == 1;
             // fragment addresses of this chunk: tile buffer tpar; weight buffer wpar in the even steps, the other one in the odd steps
             const unsigned tb = tlds0 + tpar * CD_TBYTES;
             int bE_ = bE48, aB_ = aB48;
@@ -404,6 +414,11 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             const unsigned apE = wlds0 + wpar * WBYTES + aB_, apO = wlds0 + (wpar ^ 1) * WBYTES + aB_;
             // loader state of this chunk.  weights: the slice of tap t+1 goes to the buffer step t does NOT read; wso = its byte offset
             // (this wave's first piece), advanced by one tap per step.  tiles: the rows of the next chunk / the next tile's first chunk.
+            // First step of a TILE (waves 0-1): its weight slice (tap 1) was requested BEFORE the previous tile's epilogue (below; the very
+            // first one by the start-up code), so the step issues nothing and its barrier waits with vmcnt(N), N = the memory instructions
+            // the epilogue issued behind that request (vmcnt counts in order: the slice has landed, the epilogue's stores may still be on
+            // their way).  As a fetch issued in step 0 it sat behind those stores in the counter, and the step waited for their round trip.
+            const bool wfirst = c == 0;
             int wso = 0;
             unsigned wdA = 0, wdB = 0;
             if constexpr (WL) {
@@ -421,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             auto body = [&](auto FULLc, auto PFULLc) __attribute__((always_inline)) {
                 constexpr bool FULL = decltype(FULLc)::value != 0, PFULL = decltype(PFULLc)::value != 0;
                 constexpr int KS = FULL ? 3 : 1;
-                constexpr bool MV = MOVE && FULL;
+                constexpr bool MV = MOVE && FULL && KIND != 0;      // (the multi-body form has no registers to spare for fragments that live across steps)
                 half8 fa[2][MT], fb[2][2];
                 auto gap = [&](auto Tc, auto Ic) __attribute__((always_inline)) {
                     constexpr int T = decltype(Tc)::value, i = decltype(Ic)::value;
@@ -432,7 +447,10 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                             if constexpr (i == 0) wso += wts;
                             cd_static_for<NP>([&](auto jc) {
                                 constexpr int j = decltype(jc)::value;
-                                if constexpr ((j < G - 1 ? j : G - 1) == i) wpiece(FULLc, jc, (T & 1) ? wdA : wdB, wso);
+                                if constexpr ((j < G - 1 ? j : G - 1) == i) {
+                                    if constexpr (T == 0) { if (!wfirst) wpiece(FULLc, jc, wdB, wso); }
+                                    else wpiece(FULLc, jc, (T & 1) ? wdA : wdB, wso);
+                                }
                             });
                         } else if constexpr (i == 0) {
                             if (pf) wslice(pf_full, wlds0 + (wpar ^ 1) * WBYTES, wchunk(pc));
@@ -451,7 +469,12 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                 };
                 auto sync = [&](auto Tc) __attribute__((always_inline)) {
                     constexpr int T = decltype(Tc)::value;
-                    if (WL || T == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if constexpr (WL && T == 0) {
+                        // (N: what the DIRECT epilogue of a whole MT*32-channel block issues per wave and tile; any other epilogue: 0)
+                        constexpr int NEPI = HAS_UPS ? 0 : 4 * MT * (1 + (HAS_ADD ? 1 : 0) + (HAS_MASK ? 1 : 0) + (SOUT ? 1 : 0));
+                        if (wfirst && NEPI > 0 && cpp == 4 * MT && !CD_ABL(x, 8 | 1024)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NEPI) : "memory");
+                        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    } else if (WL || T == 8) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                     __builtin_amdgcn_s_barrier();
                 };
                 auto step = [&](auto Tc) __attribute__((always_inline)) {
@@ -492,9 +515,12 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                         }
                     } else sync(Tc);
                 };
-                cd_static_for<9>(step);
+                step(cd_ic<0>{});
+                stamp();          // (tuning builds: the chunk's first step on its own -- it is the one that waits for the epilogue's stores)
+                cd_static_for<8>([&](auto tc) { step(cd_ic<decltype(tc)::value + 1>{}); });
             };
-            if constexpr (WL) {
+            if constexpr (CF != 2 && PFK != 2) body(cd_ic<CF>{}, cd_ic<PFK>{});
+            else if constexpr (WL) {
                 if (cfull) body(cd_ic<1>{}, cd_ic<1>{}); else body(cd_ic<0>{}, cd_ic<1>{});
             } else if (cfull) {
                 if (pf_full) body(cd_ic<1>{}, cd_ic<1>{}); else body(cd_ic<1>{}, cd_ic<0>{});
@@ -503,6 +529,18 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
             }
             tpar ^= 1; wpar ^= 1;
             stamp();
+        };
+        if constexpr (KIND == 1) {
+            for (int c = 0; c < nch; ++c) chunk(c, cd_ic<1>{}, cd_ic<1>{});
+        } else if constexpr (KIND == 2) {
+            for (int c = 0; c + 1 < x.nfull; ++c) chunk(c, cd_ic<1>{}, cd_ic<1>{});
+            chunk(x.nfull - 1, cd_ic<1>{}, cd_ic<0>{});
+            chunk(x.nfull, cd_ic<0>{}, cd_ic<1>{});
+        } else {
+            for (int c = 0; c < nch; ++c) chunk(c, cd_ic<2>{}, cd_ic<2>{});
+        }
+        if constexpr (WL) {
+            if (has_next) wslice(KIND != 0 || 0 < x.nfull, wlds0 + (wpar ^ 1) * WBYTES, wchunk(0) + wts);      // next tile, tap 1 (see `wfirst`)
         }
         // ---- epilogue, direct form (round 5; every variant but the fused UPSUM_BWD, whose 2x2 sums need the transposed tile): after the
         // permlane swap lane (pixel l31, kh) holds the whole 16-byte piece mt*4 + 2gp + kh of its pixel -- it stores it straight from
@@ -511,7 +549,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         // (mt, gp) + the pass's scalar base as soffset: no LDS round trip (24 LDS ops, their waits), no per-piece address arithmetic
         // (~170 VALU per wave and tile), sign byte in 13 instead of ~28 instructions: ~890 -> ~450 instructions per wave and tile in the
         // forward role, ~990 -> ~530 in the data-gradient role (no LeakyReLU there: compile-time), measured in tools/ab_libs.sh.
-        if (!CD_ABL(x, 8) && !HAS_UPS && (cpp & 1) == 0) {
+        if (!CD_ABL(x, 8) && !HAS_UPS && (cpp & 1) == 0 && !CD_ABL(x, 1024)) {
             const int pix_t = (cur.n * a.H + cur.y0 + 4 * w) * a.W + cur.x0;     // first pixel of this wave's 4 rows
             // pieces come in pairs (2i, 2i+1); their count as a SCALAR integer: compared against the loop index it is s_cmp + s_cbranch_scc (as
             // `i * 2 >= cpp` the allocator kept the comparison as a spilled lane mask and re-made it through v_cndmask / v_cmp per piece)
@@ -529,6 +567,22 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                 ur_ju = r == 3 ? 1 : (r == 1 ? -1 : 0); ur_jv = r == 0 ? 1 : (r == 2 ? -1 : 0);
                 const int i0 = r >= 2 ? P1 : 0, j0 = (r == 1 || r == 2) ? P1 : 0;
                 ur_base = (((cur.n - r * Bq) * a.H + i0) * a.W + j0) * a.urot.cs + a.urot.co + r * a.M;
+            }
+            // sign-byte form of the LeakyReLU' operand: the bytes of BOTH passes are requested up front (12 one-byte loads: one exposed round
+            // trip per tile instead of one per pass)
+            constexpr bool HOIST = HAS_MASK && SMASK && !HAS_ADD && !UROT;
+            unsigned mbh[2][MT * 2];
+            if constexpr (HOIST) {
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int pix_p = pix_t + 2 * nt * a.W;
+                    const int s_so = __builtin_amdgcn_readfirstlane(pix_p * (a.M >> 3) + (x.m_base >> 3));
+#pragma unroll
+                    for (int i = 0; i < MT * 2; ++i) {
+                        if (i >= npair) break;
+                        mbh[nt][i] = __builtin_amdgcn_raw_buffer_load_b8(rs_ms, lpix * (a.M >> 3) + kh + i * 2, s_so, 0);
+                    }
+                }
             }
             auto pass = [&](auto NtC, auto ActC) __attribute__((always_inline)) {
                 constexpr int nt = decltype(NtC)::value;
@@ -556,7 +610,9 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                     if constexpr (HAS_ADD)
                         ab[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_add, lpix * a.add.cs * 2 + kh * 16 + i * 32,
                                                                       __builtin_amdgcn_readfirstlane((pix_p * a.add.cs + a.add.co + x.m_base) * 2), 0);
-                    if constexpr (HAS_MASK && SMASK)
+                    if constexpr (HOIST)
+                        mb[i][0] = mbh[nt][i];
+                    else if constexpr (HAS_MASK && SMASK)
                         mb[i][0] = __builtin_amdgcn_raw_buffer_load_b8(rs_ms, s_lane + i * 2, s_so, 0);
                     else if constexpr (HAS_MASK)
                         mb[i] = __builtin_amdgcn_raw_buffer_load_b128(rs_mask, lpix * a.mask.cs * 2 + kh * 16 + i * 32,
@@ -625,7 +681,8 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
                                 o[q] = BF ? pack_bf16x2(v0, v1) : pack_f16x2(v0, v1);
                             }
                         }
-                        __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, d_lane + i * 32, d_so, 0);
+                        if (CD_ABL(x, 256)) __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, d_lane + i * 32, d_so, 2);
+                        else __builtin_amdgcn_raw_buffer_store_b128(o, rs_dst, d_lane + i * 32, d_so, 0);
                         // A 16-byte store reads its data registers some cycles after it issued -- more than the two wait states the
                         // compiler pads when the memory pipeline is backed up (here: behind the LDS-DMA streams and 11 other stores): a
                         // VALU write to `o` five instructions later reached HBM in ~1e-5 of the pieces (round 6, tools/r6_ab3.sh).
@@ -837,7 +894,7 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         if (!has_next) break;
         // LDS form of the epilogue: the dead buffer becomes the target of the next tile fetches (issued from step 0 on): every wave must be done
         // with it.  (The direct form touches no tile buffer: the barrier of the tile's last step is enough.)
-        if (CD_EXP_BARRIER || HAS_UPS || (cpp & 1)) __builtin_amdgcn_s_barrier();
+        if (CD_ABL(x, 1024) || HAS_UPS || (cpp & 1)) __builtin_amdgcn_s_barrier();
         item = nitem; kt = nkt; cur = nxt;
     }
     };
@@ -902,12 +959,12 @@ bool conv_dma_signs(const ssdn_conv_args* a) {
 
 int conv_dma_lds_bytes(int mt) { return 2 * CD_TBYTES + 2 * mt * 32 * 96; }
 
-template <int MT, bool BF, int EPI>
-static int cd_launch(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
+template <int MT, bool BF, int EPI, int KIND>
+static int cd_launch_kind(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
     static bool attr_set_dev[SSDN_MAX_DEVICES_ATTR] = {};
     bool& attr_set = attr_set_dev[ssdn_current_device_slot()];   // (function attributes are per device)
     if (!attr_set) {
-        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_cdma<MT, BF, EPI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        SSDN_CHECK_HIP(hipFuncSetAttribute((const void*)k_cdma<MT, BF, EPI, KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
     int cus = ssdn_device_cus();
@@ -928,9 +985,17 @@ static int cd_launch(const ssdn_conv_args* a, CdAux x, hipStream_t s) {
     const double flops = 2.0 * px * x.m_cnt * kreal * 9;
     const double bytes = px * (a->c0 * 2.0 / (a->up0 ? 4.0 : 1.0) + a->c1 * 2.0) + px * x.m_cnt * 2.0;
     prof_begin(MT == 3 ? SSDN_PROF_CDMA_MT3 : SSDN_PROF_CDMA_MT21, s);
-    SSDN_LAUNCH((k_cdma<MT, BF, EPI>), dim3(grid), dim3(256), conv_dma_lds_bytes(MT), s, *a, x);
+    SSDN_LAUNCH((k_cdma<MT, BF, EPI, KIND>), dim3(grid), dim3(256), conv_dma_lds_bytes(MT), s, *a, x);
     prof_end(MT == 3 ? SSDN_PROF_CDMA_MT3 : SSDN_PROF_CDMA_MT21, s, flops, bytes);
     return 0;
+}
+template <int MT, bool BF, int EPI>
+static int cd_launch(const ssdn_conv_args* a, const CdAux& x, hipStream_t s) {
+    if (x.tail16 == 0 && x.nfull > 0) return cd_launch_kind<MT, BF, EPI, 1>(a, x, s);
+    if constexpr (!BF) {      // (a 16-channel tail behind full chunks: the forward role of decode_block_1.0; anything else takes the general form)
+        if (x.tail16 == 1 && x.nfull > 0) return cd_launch_kind<MT, BF, EPI, 2>(a, x, s);
+    }
+    return cd_launch_kind<MT, BF, EPI, 0>(a, x, s);
 }
 
 template <int MT>

@@ -147,6 +147,20 @@ def trace(layer="decode_block_1.2", role="fwd"):
     lib.ssdn_debug_set_trace(None)
     t = buf.cpu().view(-1, 32).numpy()
     t = t[t[:, 0] > 0]
+    if (t[:, 31] >> 32).any():          # k_cdma tuning builds: HW_ID of wave 0 in the last slot
+        hw = (t[:, 31] & 0xffffffff).astype(np.int64)
+        t = t.copy(); t[:, 31] = 0
+        f = lambda lo, n: (hw >> lo) & ((1 << n) - 1)
+        import collections
+        print("HW_ID fields: wave_id", sorted(collections.Counter(f(0, 4)).items()), " simd", sorted(collections.Counter(f(4, 2)).items()),
+              " cu", len(set(f(8, 4))), " sh", sorted(collections.Counter(f(12, 1)).items()), " se", sorted(collections.Counter(f(13, 3)).items()),
+              " tg_id", sorted(collections.Counter(f(16, 4)).items()))
+        # start offsets inside one XCD (its own clock): workgroups b % 8 == 0
+        g = t[0::8]
+        off = np.sort(g[:, 0] - g[:, 0].min())
+        print("XCD 0: start offsets of its %d workgroups (ticks):" % len(g), [int(v) for v in off[::max(1, len(off) // 16)]])
+        tg = ((hw[0::8] >> 16) & 1)
+        print("XCD 0: mean start offset by tg_id parity:", [float((g[:, 0] - g[:, 0].min())[tg == k].mean()) if (tg == k).any() else None for k in (0, 1)])
     t0 = t[:, 0].min()
     nst = int((t[0] > 0).sum())
     d = np.diff(t[:, :nst], axis=1)
