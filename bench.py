@@ -247,6 +247,17 @@ def run_rank(args):
     import torch.distributed as dist
 
     stub = os.environ.get("SSDN_BENCH_STUB") == "1"
+    # SSDN_DP_PLAN=split|buckets|all: which weight-gradient plan the benchmarked engines are built with, so that a
+    # driver-side scaling run can compare them without editing source -- "split" (default: the head bucket's weight gradients on the side
+    # lane, everything else one chip-wide launch: the fastest single-GPU step; 4.33 MB of the exchange sit behind the backward pass),
+    # "buckets" (one launch per gradient bucket: every bucket's all-reduce runs under the next bucket's launch, at ~13 % more single-GPU
+    # time).  The package itself never reads the environment (ssdn.hip.graph: planner constants); the choice is echoed in the line.
+    dp_plan = os.environ.get("SSDN_DP_PLAN", "split")
+    if dp_plan not in ("split", "buckets", "all"):
+        raise RuntimeError("SSDN_DP_PLAN must be split, buckets or all (got %r)" % dp_plan)
+    if not stub:
+        from ssdn.hip import graph as _graph
+        _graph.WGRAD_MEGA = dp_plan
     # SSDN_BENCH_BACKEND=gloo: ranks may share a GPU (device = LOCAL_RANK mod visible GPUs) and exchange device tensors through
     # gloo -- how the whole N-rank path is exercised on the 1-GPU test boxes; RCCL itself refuses two ranks on one device
     backend = "gloo" if stub else os.environ.get("SSDN_BENCH_BACKEND")
@@ -463,7 +474,7 @@ def run_rank(args):
             "data": "synthetic (clean uint8 patches U{0..255} in pinned host memory, uploaded EVERY step; clipped gauss25 noise made on the "
                     "device; random-init weights)",
             "config": {"workload": "ssdn gauss25 sigma_known, %dx%d RGB patches, batch %d per GPU, H2D of the minibatch + device noise + blind-spot U-Net fwd+bwd + posterior head + Adam" % (P, P, B),
-                       "global_batch": B * world, "parallelism": "dp%d" % world,
+                       "global_batch": B * world, "parallelism": "dp%d" % world, "dp_plan": dp_plan,
                        "achieved_train_tflops_algorithmic": round(value * TRAIN_GFLOP_PER_PATCH / 1e3, 2)},
         }
         if world > 1:

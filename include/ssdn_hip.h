@@ -468,6 +468,12 @@ typedef struct ssdn_noise_args {
 /* Execute `n` ops in order on `stream`.  Returns 0 or a negative error (ssdn_last_error()). */
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream);
 
+/* Order two caller streams: everything enqueued on `then` AFTER this call starts after everything enqueued on `first` BEFORE it (one event
+ * of the executor's ring: hipEventRecord on `first`, hipStreamWaitEvent on `then`).  How two independent op lists run concurrently and meet
+ * again -- the sigma-estimation network's lists beside the main network's (replaces the sequential execution of the two nn.Modules in
+ * ssdn/ssdn/denoiser.py:261-265; DenoiserEngine._fork_sigma): order(main, side); run(list, side); order(side, main). */
+int ssdn_stream_order(void* first, void* then);
+
 /* Bytes of dynamic LDS a conv op will request (host-side check of a tiling), or < 0 if the tiling is invalid. */
 int ssdn_conv_lds_bytes(const ssdn_conv_args* a);
 int ssdn_wgrad_lds_bytes(const ssdn_wgrad_args* a);

@@ -190,6 +190,15 @@ static LaneSet* lanes_get() {
 // lanes a lane is ordered after (bit l = lane l): see ssdn_op in the header
 static const unsigned g_lane_deps[SSDN_NLANES] = {0u, 1u << 0, (1u << 0) | (1u << 1) | (1u << 3), 1u << 0};
 
+int ssdn_stream_order(void* first, void* then) {
+    LaneSet* LS = lanes_get();
+    if (!LS) return -1;
+    hipEvent_t e = LS->ev[LS->ev_next++ % SSDN_NEVENTS];
+    SSDN_CHECK_HIP(hipEventRecord(e, (hipStream_t)first));
+    SSDN_CHECK_HIP(hipStreamWaitEvent((hipStream_t)then, e, 0));
+    return 0;
+}
+
 int ssdn_run_ops(const ssdn_op* ops, int n, void* stream) {
     hipStream_t lane_s[SSDN_NLANES] = {(hipStream_t)stream, nullptr, nullptr, nullptr};
     g_ssdn_stop_event = nullptr;                                   // (an earlier call may have left through an error path)

@@ -658,11 +658,39 @@ class DenoiserEngine:
         if self.sigma is not None:
             self.sigma.pack.run(s)
 
+    # ---- the sigma-estimation network next to the main network (BASELINE config 3) ------------------------------------------------
+    # The two networks share only the input and meet in the loss head (reference: ssdn/ssdn/denoiser.py:76-88, 261-265: the estimator
+    # reads the noisy image, nothing of the main network).  Enqueued one behind the other on ONE stream (rounds 1-5) the small plain
+    # network -- grids of a few dozen workgroups at batch 32 -- ran alone on the chip for 0.86 ms of a 2.5 ms step.  Now its op lists go
+    # to a second stream, ordered behind what the caller's stream has enqueued so far and joined back before the consumer (loss head /
+    # optimiser): its launches fill the CUs the main network's latency-bound stages leave idle.  Every tensor the two lists write is its
+    # own (each DeviceNet owns its buffers; disjoint ranges of the flat gradient), so the results are the sequential order's, bit for bit.
+    SIGMA_CONCURRENT = 3          # bit 0: forward lists, bit 1: backward lists (True = both)
+
+    def _fork_sigma(self, s: int, oplist) -> int:
+        """run `oplist` (the sigma network's) on the side stream behind everything stream `s` holds; -> the side stream (to join on)"""
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        side = self._side.cuda_stream
+        # (the library's own event ring: the same calls through torch.cuda.Event / ExternalStream let the side stream start early in
+        #  ~3 of 10 runs -- stale upstream gradients, tools/ab_sigma_race.py; round 6)
+        L.check(L.load().ssdn_stream_order(C.c_void_p(s), C.c_void_p(side)))
+        oplist.run(side)
+        return side
+
+    def _join_sigma(self, s: int, side: int) -> None:
+        L.check(L.load().ssdn_stream_order(C.c_void_p(side), C.c_void_p(s)))
+
     def forward(self, stream=None):
         s = current_stream() if stream is None else stream
-        self.main.fwd.run(s)
-        if self.sigma is not None:
-            self.sigma.fwd.run(s)
+        if self.sigma is not None and (int(self.SIGMA_CONCURRENT) & 1):
+            ev = self._fork_sigma(s, self.sigma.fwd)
+            self.main.fwd.run(s)
+            self._join_sigma(s, ev)
+        else:
+            self.main.fwd.run(s)
+            if self.sigma is not None:
+                self.sigma.fwd.run(s)
         self.ops_loss.run(s)
 
     def net_forward_only(self, stream=None):
@@ -676,9 +704,14 @@ class DenoiserEngine:
         them in front of the optimiser launch -- the flat gradient is incomplete until then."""
         s = current_stream() if stream is None else stream
         if defer_tail and exchange is None and self.ops_opt_tail is not None:
-            self.main.bwd_head.run(s)
-            if self.sigma is not None:
-                self.sigma.bwd.run(s)
+            if self.sigma is not None and (int(self.SIGMA_CONCURRENT) & 2):
+                ev = self._fork_sigma(s, self.sigma.bwd)
+                self.main.bwd_head.run(s)
+                self._join_sigma(s, ev)
+            else:
+                self.main.bwd_head.run(s)
+                if self.sigma is not None:
+                    self.sigma.bwd.run(s)
             self._tail_pending = True
             return
         self._tail_pending = False
@@ -700,6 +733,11 @@ class DenoiserEngine:
                 self.sigma.bwd.run(s)
             if len(exchange.ranges) > NB:
                 exchange.record_here(NB)
+            return
+        if self.sigma is not None and (int(self.SIGMA_CONCURRENT) & 2):
+            ev = self._fork_sigma(s, self.sigma.bwd)
+            self.main.bwd.run(s)
+            self._join_sigma(s, ev)
             return
         self.main.bwd.run(s)
         if self.sigma is not None:

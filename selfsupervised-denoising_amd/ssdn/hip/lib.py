@@ -131,7 +131,7 @@ ARG_TYPES = dict(pack_input=PackInputArgs, conv=ConvArgs, pool_fwd=PoolArgs, poo
 # every symbol include/ssdn_hip.h declares
 ABI_VERSION = 14      # SSDN_ABI_VERSION of include/ssdn_hip.h this binding mirrors
 
-SYMBOLS = ["ssdn_run_ops", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
+SYMBOLS = ["ssdn_run_ops", "ssdn_stream_order", "ssdn_conv_lds_bytes", "ssdn_wgrad_lds_bytes", "ssdn_abi_version", "ssdn_last_error",
            "ssdn_device_cus", "ssdn_probe_mfma", "ssdn_probe_tr16", "ssdn_struct_size", "ssdn_profile_enable",
            "ssdn_profile_read", "ssdn_profile_set_stride", "ssdn_debug_set_trace", "ssdn_debug_get_trace", "ssdn_conv_set_mode",
            "ssdn_wgrad_mergeable", "ssdn_conv_fuses_pool", "ssdn_conv_fuses_upsum", "ssdn_conv_fuses_unrot", "ssdn_conv_fuses_urot", "ssdn_conv_signs", "ssdn_chain_len",
@@ -171,6 +171,8 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.ssdn_run_ops.argtypes = [C.POINTER(OpRec), C.c_int, vp]
     lib.ssdn_run_ops.restype = C.c_int
+    lib.ssdn_stream_order.argtypes = [vp, vp]
+    lib.ssdn_stream_order.restype = C.c_int
     lib.ssdn_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
     lib.ssdn_conv_lds_bytes.restype = C.c_int
     lib.ssdn_wgrad_lds_bytes.argtypes = [C.POINTER(WgradArgs)]

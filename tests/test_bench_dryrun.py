@@ -31,12 +31,21 @@ def test_bench_gpus2_self_spawns_and_prints_one_line():
     r = json.loads(lines[0])
     assert r["n_gpus"] == 2 and r["steps"] == 3 and r["warmup"] == 1 and r["stub"] is True
     assert r["value"] > 0 and r["unit"] == "patches/s" and r["scaling"] == "weak" and r["higher_is_better"] is True
-    assert r["config"]["global_batch"] == 64 and r["config"]["parallelism"] == "dp2"
+    assert r["config"]["global_batch"] == 64 and r["config"]["parallelism"] == "dp2" and r["config"]["dp_plan"] == "split"
     assert abs(r["value"] - 3 * 64 / (r["ms_per_step"] * 3 / 1e3)) < 1e-2 * r["value"]
     assert "resident" not in r["data"]
     # N > 1: the line says how long the optimiser waited for the gradient exchange behind the backward pass
     assert r["allreduce_exposed_us"] is not None and r["allreduce_exposed_us"] >= 0 and r["allreduce"]["steps"] == 20
     assert sum(r["allreduce"]["collectives_per_step_bytes"]) == 4 * 1269129
+
+
+def test_bench_dp_plan_is_echoed():
+    """SSDN_DP_PLAN picks the weight-gradient plan of the benchmarked engines (a scaling run can A/B "split" against "buckets")."""
+    p, lines = _run({"SSDN_BENCH_STUB": "1", "SSDN_DP_PLAN": "buckets"}, "--steps", "2", "--warmup", "1")
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert json.loads(lines[-1])["config"]["dp_plan"] == "buckets"
+    p, lines = _run({"SSDN_BENCH_STUB": "1", "SSDN_DP_PLAN": "nonsense"}, "--steps", "2", "--warmup", "1")
+    assert p.returncode != 0 and "error" in json.loads(lines[-1])
 
 
 def test_bench_single_rank_stub_line():

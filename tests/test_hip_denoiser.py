@@ -421,3 +421,42 @@ def test_device_metric_accumulators_equal_the_host_formulas(alg, style, mode):
         assert count == m.n, (name, count, m.n)
         assert float(total) == pytest.approx(float(torch.as_tensor(m.total).sum()), rel=1e-5, abs=1e-6), name
     assert d.read_metrics("train") == {}                       # reset
+
+
+def test_sigma_network_beside_the_main_network_is_bit_identical():
+    """BASELINE config 3 (sigma estimated per image by a second network): the estimator's op lists run on a second stream beside the main
+    network's (DenoiserEngine.SIGMA_CONCURRENT, ordered by ssdn_stream_order) -- every step's flat gradient and the parameters after three
+    steps are bit-identical to the sequential order's, run after run.  (The first version ordered the streams through torch.cuda.Event /
+    ExternalStream: in ~3 of 10 runs the estimator's backward list started before the loss head had written its upstream gradient.)
+    Replaces the two sequential nn.Module calls of ssdn/ssdn/denoiser.py:261-265."""
+    import torch
+    from ssdn.datasets import NoisyDataset
+    from ssdn.hip.engine import DenoiserEngine
+    B, P, steps = 32, 64, 3
+    g = torch.Generator().manual_seed(3)
+    clean = torch.rand(B, 3, P, P, generator=g)
+    noisy = (clean + torch.randn(B, 3, P, P, generator=g) * 0.1).clamp(0, 1)
+    MD = NoisyDataset.Metadata
+    saved = DenoiserEngine.SIGMA_CONCURRENT
+
+    def run(mode):
+        DenoiserEngine.SIGMA_CONCURRENT = mode
+        torch.manual_seed(0)
+        d = make_denoiser("ssdn", "gauss25", "var", 3)
+        d.train()
+        grads = []
+        for _ in range(steps):
+            d.train_step([noisy.cuda(), None, {MD.INPUT_NOISE_VALUES: torch.full((B, 1, 1, 1), 0.1), MD.CLEAN: clean.cuda()}], 3e-4)
+            torch.cuda.synchronize()
+            grads.append(d.flat_grad.clone())
+        return d.flat.clone(), grads
+    try:
+        seq, gseq = run(0)
+        assert float(gseq[1][-(2 + 1102177):].abs().max()) > 0          # (the estimator's gradients carry signal from the second step on)
+        for rep in range(6):
+            con, gcon = run(3)
+            for i in range(steps):
+                assert torch.equal(gseq[i], gcon[i]), "run %d, step %d: %d gradient elements differ" % (rep, i, int((gseq[i] != gcon[i]).sum()))
+            assert torch.equal(seq, con)
+    finally:
+        DenoiserEngine.SIGMA_CONCURRENT = saved

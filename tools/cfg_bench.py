@@ -22,8 +22,15 @@ if os.environ.get("WGRAD_MEGA"):          # A/B aid: plan variant ("all", "split
     from ssdn.hip import graph as _G
     _G.WGRAD_MEGA = None if os.environ["WGRAD_MEGA"] == "none" else os.environ["WGRAD_MEGA"]
     print("WGRAD_MEGA =", _G.WGRAD_MEGA)
+if os.environ.get("SIGMA_CONCURRENT") is not None:          # A/B aid: the sigma-estimation network's lists on a second stream (1) or behind the main net's (0)
+    from ssdn.hip.engine import DenoiserEngine as _DE
+    _DE.SIGMA_CONCURRENT = int(os.environ["SIGMA_CONCURRENT"])
+    print("SIGMA_CONCURRENT =", _DE.SIGMA_CONCURRENT)
+only = os.environ.get("CFG_ONLY")                            # e.g. CFG_ONLY="config 3"
 dev = torch.device("cuda", 0)
 for tag, alg, style, mode, ch, B, P in CONFIGS:
+    if only and not tag.startswith(only):
+        continue
     cfg = ssdn.cfg.base()
     cfg[ConfigValue.ALGORITHM] = NoiseAlgorithm(alg)
     cfg[ConfigValue.NOISE_STYLE] = style
