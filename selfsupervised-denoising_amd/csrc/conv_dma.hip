@@ -932,11 +932,14 @@ bool conv_dma_eligible(const ssdn_conv_args* a, bool any_size) {
     if (a->urot.p && (a->bf16 || a->M != 96 || a->Mpad != 96 || a->H != a->W || (a->N & 3) || a->mask.p || a->add.p || a->upsum.p || a->pool.p ||
                       (a->urot.co & 7) || (a->urot.cs & 7) || (long long)(a->N / 4) * a->H * a->W * a->urot.cs * 2 >= (1ll << 31))) return false;
     if (a->upsum.p && (!a->bf16 || a->mask.p || a->add.p || a->upsum_c % 96 || a->upsum_c > a->M)) return false;
-    // persistent grid: worth it from about one 256-pixel tile per CU upwards (smaller layers: k_conv's 32-channel blocks)
+    // worth it from one 256-pixel tile per CU upwards, and from one per TWO CUs where an image is more than one tile (round 6: the plain
+    // network's 32x32 stage at batch 32; not the blind-spot network's 16x16 stage, which runs beside the half-chip weight-gradient launch:
+    // ssdn/hip/graph.py::cdma_fills mirrors the rule and says what was measured)
     int cus = ssdn_device_cus();
     if (cus <= 0) cus = 256;
     const long long tiles = (long long)a->N * (a->H >> 4) * (a->W >> 4);
-    if (tiles < cus && !any_size) return false;
+    if (!(tiles >= cus || (2 * tiles >= cus && a->H * a->W > 256)) && !any_size) return false;
+    if ((long long)a->N * (a->W >> 4) >= 65536) return false;    // (strips: the tile walk's reciprocal multiply, CdAux.tx_magic)
     int csmax = a->dst.cs > a->src1.cs ? a->dst.cs : a->src1.cs;
     csmax = csmax > a->src0.cs ? csmax : a->src0.cs;
     csmax = csmax > a->mask.cs ? csmax : a->mask.cs;

@@ -177,6 +177,15 @@ def _pow2ceil_log(v: int) -> int:
     return l
 
 
+def cdma_fills(tiles: int, cus: int, H: int = 0, W: int = 0) -> bool:
+    """csrc/conv_dma.hip::conv_dma_eligible's size rule: k_cdma serves a 3x3 layer from one 16x16-pixel tile per CU upwards -- and from one
+    tile per TWO CUs where an image is more than one tile (round 6: the plain network's 32x32 stage at batch 32, 128 tiles: config 4's step
+    0.89 -> 0.83 ms).  Not the blind-spot network's 16x16 stage (also 128 tiles, one per image): alone its launches are 4-6 us faster on
+    k_cdma than on k_conv's flat path (tools/r6_mode2.py), inside the step -- beside the half-chip weight-gradient launch, whose blocks and
+    k_cdma's workgroups cannot share a CU's LDS -- the step was 1.5 % slower."""
+    return tiles >= cus or (2 * tiles >= cus and H * W > 256)
+
+
 def choose_conv_tile(N, H, W, taps, Ktot, Mpad, budget=LDS_LIMIT, out16=True, cus=256):
     """Pick (ltw, lth, ltn, kc) for SSDN_OP_CONV: <= 256 pixels per workgroup, LDS = halo tile + two weight slices.
     Layers with at most one pixel tile per CU run as 32-output-channel blocks (the library's rule, conv_uses_mt1): one
@@ -343,7 +352,7 @@ class NetPlan:
         fused = pool is not None and conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus)
         if upsum is not None:
             # fused SSDN_OP_UPSUM_BWD: k_cdma (>= one 16x16 tile per CU, whole 96-channel blocks) or k_conv's flat path
-            dma = (len(taps) == 9 and H % 16 == 0 and W % 16 == 0 and N * (H // 16) * (W // 16) >= self.dev_cus and
+            dma = (len(taps) == 9 and H % 16 == 0 and W % 16 == 0 and cdma_fills(N * (H // 16) * (W // 16), self.dev_cus, H, W) and
                    Ktot % 48 in (0, 16) and upsum_c % 96 == 0)
             fused = (dma or conv_fuses_pool(N, H, W, taps, Ktot, M, Mpad, ltw, lth, ltn, kc, self.dev_cus)) and upsum_c % 8 == 0 and \
                 mask is None and add is None
@@ -496,7 +505,7 @@ class NetPlan:
 
         def cdma_serves(h, w, ktot):
             """csrc/conv_dma.hip::conv_dma_eligible for the 3x3 layers of this network at h x w"""
-            return h % 16 == 0 and w % 16 == 0 and N * (h // 16) * (w // 16) >= self.dev_cus and ktot % 48 in (0, 16)
+            return h % 16 == 0 and w % 16 == 0 and cdma_fills(N * (h // 16) * (w // 16), self.dev_cus, h, w) and ktot % 48 in (0, 16)
 
         def sign_of(t, h, w, C_, ktot_fwd, thin=False):
             ok = self.train and SIGN_BYTES_CONV and cdma_serves(h, w, C_) and \
@@ -563,7 +572,7 @@ class NetPlan:
             # decode_block_1.2 stores straight into `u` where the library's k_cdma serves it (csrc/conv_dma.hip::conv_dma_eligible:
             # >= one 16x16 tile per CU; the engine cross-checks with ssdn_conv_fuses_urot).  d1b then never exists, so a training
             # plan needs the sign bytes for its backward pass.
-            fused_urot = (FUSE_UNROT_FWD and H == W and H % 16 == 0 and N * (H // 16) * (W // 16) >= self.dev_cus and
+            fused_urot = (FUSE_UNROT_FWD and H == W and H % 16 == 0 and cdma_fills(N * (H // 16) * (W // 16), self.dev_cus, H, W) and
                           B * H * W * 384 * 2 < (1 << 31) and (smk is not None or not self.train))
             d1a, d1b = dec("d1a", "d1b", "decode_block_1.0", "decode_block_1.2", d2b, 96, x16, 16, H, W,
                            urot=u if fused_urot else None, urot_smask=smk if fused_urot else None)

@@ -160,6 +160,10 @@ def test_baseline_plan_keeps_sign_bytes_and_route_words_instead_of_activation_re
     assert b["encode_block_1.2"]["mask_sign"] == "m/smk_e0" and b["decode_block_1.2"]["mask_sign"] == "m/smk_d1a"
     assert b["decode_block_2.2"]["mask_sign"] == "m/smk_d2a" and b["output_block.2"]["mask_sign"] == "m/smk_na"
     assert b["decode_block_1.0"]["upsum_mask_sign"] == "m/smk_d2b" and b["decode_block_2.0"].get("upsum_mask_sign") is None
+    # round 6: k_cdma also serves a stage with one tile per TWO CUs where an image is more than one tile (graph.cdma_fills) -- the plain
+    # network's 32x32 stage at batch 32 (config 4), not the blind-spot network's 16x16 stage
+    from ssdn.hip import graph as G
+    assert G.cdma_fills(128, 256, 32, 32) and not G.cdma_fills(128, 256, 16, 16) and G.cdma_fills(512, 256, 16, 16)
     assert b["output_block.0"]["unrot_smask"] == "m/smk_d1b"
     pools = [op.a for op in plan.fwd if op.type == "pool_fwd"]
     assert [bool(a.get("route")) for a in pools] == [True, False]          # 64x64 -> 32x32 stand-alone; 32x32 -> 16x16: its backward is chained
