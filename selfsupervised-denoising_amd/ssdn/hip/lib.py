@@ -171,8 +171,9 @@ def load() -> C.CDLL:
     lib = C.CDLL(LIB_PATH)
     lib.ssdn_run_ops.argtypes = [C.POINTER(OpRec), C.c_int, vp]
     lib.ssdn_run_ops.restype = C.c_int
-    lib.ssdn_stream_order.argtypes = [vp, vp]
-    lib.ssdn_stream_order.restype = C.c_int
+    if hasattr(lib, "ssdn_stream_order"):        # (tools/ab_libs.sh loads older builds of the library through SSDN_HIP_LIB)
+        lib.ssdn_stream_order.argtypes = [vp, vp]
+        lib.ssdn_stream_order.restype = C.c_int
     lib.ssdn_conv_lds_bytes.argtypes = [C.POINTER(ConvArgs)]
     lib.ssdn_conv_lds_bytes.restype = C.c_int
     lib.ssdn_wgrad_lds_bytes.argtypes = [C.POINTER(WgradArgs)]
