@@ -377,6 +377,20 @@ def run_rank(args):
                                   "tflops_algorithmic": round(f2.value / 1e12 / (m2.value / 1e3), 1) if m2.value > 0 else None,
                                   "launches_per_step": round(c2.value * FAM_STRIDE / FAM_STEPS, 1),
                                   "ms_per_step_bracketed_sum": round(m2.value * FAM_STRIDE / FAM_STEPS, 4)}
+    # (a1) the dominant kernel's ALGORITHMIC bytes per launch on one basis (the sampled launches' mean depended on which of
+    # the eight launches of a step the samples fell on -- 109.9 MB in a 20-step run, 116.9 MB in a 100-step one): ONE extra step with every
+    # launch of the family counted, i.e. the exact mean over the step's eight launches (inputs read once + outputs written once)
+    alg_bytes_exact = None
+    if lib is not None:
+        lib.ssdn_profile_enable(prof_kind, 64)
+        lib.ssdn_profile_set_stride(prof_kind, 1)
+        step(0)
+        sync()
+        m3, c3, f3, b3 = C.c_double(), C.c_longlong(), C.c_double(), C.c_double()
+        L.check(lib.ssdn_profile_read(prof_kind, C.byref(m3), C.byref(c3), C.byref(f3), C.byref(b3)))
+        lib.ssdn_profile_enable(prof_kind, 0)
+        if c3.value:
+            alg_bytes_exact = int(b3.value / c3.value)
     # (a2) N > 1: how long the optimiser stream WAITS for the gradient exchange behind the last slab reduction (events on the compute
     # stream around launch + finish of ssdn.hip.dp.exchange_step: last k_wreduce_multi -> k_adam_pack), median of EXP_STEPS extra steps
     exposed = None
@@ -490,7 +504,8 @@ def run_rank(args):
                                "frac": round(achieved / MFMA_FP16_DENSE_PEAK_TFLOPS, 4), "traffic": traffic,
                                "traffic_unit": "HBM-side bytes per launch, rocprofv3 FETCH_SIZE*2 + WRITE_SIZE from separate --pmc passes over this "
                                                "command; NOT measured in this run: %s" % traffic_src,
-                               "algorithmic_bytes_per_launch": int(by.value / max(1, cnt.value)),
+                               "algorithmic_bytes_per_launch": alg_bytes_exact if alg_bytes_exact else int(by.value / max(1, cnt.value)),
+                               "algorithmic_bytes_basis": "mean over ALL launches of the family in one step (every input read once + every output written once; one extra step after the timed region with every launch counted)",
                                "launches": int(cnt.value), "sampling": "every %dth launch of the timed region; the two HIP events of a sample ride on the sampled launch's own dispatch (hipExtLaunchKernelGGL start / stop event: the kernel's duration as a kernel trace reports it)" % PROF_STRIDE, "avg_launch_us": round(1e3 * ms.value / max(1, cnt.value), 3),
                                "kernel_time_share": round(PROF_STRIDE * ms.value / 1e3 / dt, 4)}
             res["families"] = families
