@@ -12,24 +12,29 @@
 //     matrix cores; ONE raw s_barrier per step (a step = one tap x one chunk = 18 MFMAs per wave).
 //   * Loader ROLES by wave: waves 0-1 fetch the weight slices, waves 2-3 the halo tiles.  vmcnt is one in-order counter per
 //     wave: a wave that issued both kinds would have to wait for a just-issued tile fetch (HBM latency) whenever it needs the
-//     weights of the next step (measured: +20 % launch time).  With roles, the weight waves drain their short queue every step
-//     and the tile waves only once per chunk, eight steps after their first fetch.
+//     weights of the next step (measured: +20 % launch time).  Since round 6 each role runs its OWN copy of the whole tile walk
+//     (`run<WL>`): no wave-uniform role branch inside a step.
 //   * LDS images are unpadded (DMA writes 64 consecutive 16-byte pieces per wave instruction) and XOR-swizzled on the SOURCE
 //     side: piece c of halo pixel (hy, hx) sits at piece c ^ (hy & 1); piece c of weight row m at c ^ ((m >> 3) & 1).  Checked by
 //     brute force over the ds_read_b128 lane groups: every fragment read is bank-conflict free.
-//   * Tile fetches are row items: one halo row = two 54-lane DMA instructions whose per-lane offsets never change.
-//   * Fragment addresses are one VGPR base + compile-time immediates (the 9 steps of a chunk are unrolled): per step a wave
-//     issues 18 MFMAs, 15 ds_read_b128, a few DMA instructions and their scalar bookkeeping: ~85 instructions beside the MFMAs
-//     (k_conv: ~300).  Over a whole launch the SQ counters say 8.4 non-MFMA instructions per MFMA in round 4 (profiles/r04_pmc_cdma_fwd.txt:
-//     4.8 VALU + 2.7 SALU + 0.9 LDS), of which the epilogue and the per-tile head are more than half; round 5's direct epilogue
-//     halves the epilogue's share (profiles/r05_pmc_cdma_fwd.txt).
+//   * A step = one tap of one chunk = 18 MFMAs per wave (MT = 3).  Its loader pieces sit in the GAPS behind the MFMAs of its first
+//     K-step (an MFMA occupies the matrix core for 8 issue slots; what the wave issues meanwhile is free): a weight piece is one DMA
+//     instruction (the wave's pieces of a slice share one M0 / soffset and differ by the immediate offset), a halo-row item is
+//     s_add (running soffset), s_add (M0), the DMA -- all 64 lanes active (overlapping row windows), rows issued in the chunk's first
+//     three steps.  Fragment addresses are one VGPR base + compile-time immediates; ~50 instructions beside the 18 MFMAs per step
+//     (round 5: ~120): 3.7 non-MFMA instructions per MFMA over a launch (profiles/r06_pmc_cdma_fwd.txt; round 5: 7.2, round 4: 8.4).
+//   * ONE s_barrier per step, in FRONT of the step's last K-step (every fragment of the step has been read by then); the next step's
+//     first fragments are read behind it, under those MFMAs (KIND 1 / 2; CD_MOVE_BARRIER).
+//   * Chunk kinds (48 / 16 channels) are a compile-time property of the instantiation (KIND): one unrolled body per role.  As a
+//     run-time choice between bodies the register allocator kept the accumulators in different registers per body and copied 96
+//     registers per chunk (see the comment at k_cdma).
 //   * Epilogue (round 5, every variant but the fused UPSUM_BWD): a wave owns 4 tile rows; it converts its accumulators, widens the
 //     8-byte MFMA fragments to 16-byte pieces with v_permlane32_swap and stores each piece straight from registers (one per-lane
 //     offset + an immediate per piece + a scalar base per pass; LeakyReLU sign bytes from the lane's own eight channels); the fused
-//     UPSUM_BWD still transposes through a wave-private LDS region, because its 2x2 sums cross pixels.  mask / skip-gradient
-//     operands of the data-gradient role are fetched as one batch per pass.  The other workgroup of the CU keeps the matrix cores
-//     busy meanwhile -- when it is not in its own epilogue: the two workgroups of a CU start together and stay in phase
-//     (profiles/r05_k_cpipe_experiment.txt).
+//     UPSUM_BWD still transposes through a wave-private LDS region, because its 2x2 sums cross pixels.  The sign bytes of the
+//     data-gradient role's LeakyReLU' are requested for both passes up front; the next tile's tap-1 weights are requested BEFORE the
+//     epilogue (the tile's first barrier waits with vmcnt(N)).  Every 16-byte store is followed by s_nop 7 (its data registers are
+//     read later than the compiler's two wait states when the memory pipeline is backed up: profiles/r06_store_data_hazard.txt).
 //   * bias enters as the initial value of the accumulators.
 //
 // Shape class: 9 taps forming a 3x3 window (blind-spot, plain, or either one mirrored = data gradient), H and W multiples of
