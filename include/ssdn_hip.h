@@ -559,10 +559,10 @@ int ssdn_wgrad_mergeable(const ssdn_wgrad_args* a);
  * (network + loss head), SSDN_PLAN_BACKWARD (gradients into "grads"), SSDN_PLAN_OPTIMISER (fused Adam + re-pack).  Everything is
  * enqueued asynchronously on `stream` (a hipStream_t; the library's side streams are ordered after it and joined into it).
  * Not thread-safe per plan; one plan per process / GPU.  All functions return 0 or a negative status with ssdn_last_error().
- * VALIDATED (tests/test_hip_plan_c.py): the blind-spot network with a known sigma (BASELINE config 2's plan), bit-identical to the
- * Python-driven step.  A blob concatenates the main and the sigma network's lists of a phase into ONE list (the Python path runs them
- * as separate ssdn_run_ops calls with a join between them), so plans WITH a sigma network (config 3) or with mask_mse coordinates
- * (config 4) load and run but their ordering is not covered by a test yet; ssdn_train_step also fixes gscale = 1 and Adam's
+ * VALIDATED (tests/test_hip_plan_c.py, a process that imports nothing of this repository): one rank's shard of BASELINE configs 2 (ssdn,
+ * sigma known), 3 (+ the sigma-estimation network: the blob concatenates the two networks' lists of a phase into ONE list, where the
+ * Python path runs them as separate ssdn_run_ops calls on two streams) and 4 (Noise2Void: masked MSE at the exported coordinates) -- two
+ * training steps each, loss and parameters bit-identical to the Python-driven steps.  ssdn_train_step fixes gscale = 1 and Adam's
  * betas 0.9 / 0.99 (the reference's, train.py:100-107) -- use ssdn_plan_set_lr + ssdn_plan_run for anything else. */
 #define SSDN_PLAN_REPACK 0
 #define SSDN_PLAN_FORWARD 1

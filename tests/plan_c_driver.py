@@ -43,7 +43,12 @@ def view(name, dtype):
 
 view("params", torch.float32)[:inp["params"].numel()].copy_(inp["params"])
 view("m/in32", torch.float32).copy_(inp["noisy"].reshape(-1))
-view("noise_param", torch.float32).copy_(inp["noise_param"].reshape(-1))
+if inp.get("noise_param") is not None:          # ssdn with a known noise parameter
+    view("noise_param", torch.float32).copy_(inp["noise_param"].reshape(-1))
+if inp.get("ref") is not None:                  # mse / mask_mse: the reference image
+    view("ref", torch.float32).copy_(inp["ref"].reshape(-1))
+if inp.get("coords") is not None:               # mask_mse: the masked coordinates (int64 [ncoords, 2])
+    view("coords", torch.int64).copy_(inp["coords"].reshape(-1))
 stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 ok(lib.ssdn_plan_run(plan, 0, stream))                       # SSDN_PLAN_REPACK: MFMA shadows of the parameters just written
 out = {"meta": meta, "loss": [], "params": None}
@@ -52,6 +57,7 @@ for step in range(1, inp["steps"] + 1):
     torch.cuda.synchronize()
     out["loss"].append(view("loss", torch.float32).cpu().clone())
 out["params"] = view("params", torch.float32).cpu().clone()
-out["pme"] = view("pme", torch.float32).cpu().clone()
+if meta.get("pipeline") == "ssdn":
+    out["pme"] = view("pme", torch.float32).cpu().clone()
 torch.save(out, sys.argv[4])
 print("plan_c_driver: %d steps, loss[0][:3] = %s" % (inp["steps"], out["loss"][0][:3].tolist()))
