@@ -672,8 +672,10 @@ class DenoiserEngine:
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream(device=self.device)
         side = self._side.cuda_stream
-        # (the library's own event ring: the same calls through torch.cuda.Event / ExternalStream let the side stream start early in
-        #  ~3 of 10 runs -- stale upstream gradients, tools/ab_sigma_race.py; round 6)
+        # (the library's own event ring on the RAW handles.  The first version recorded a torch.cuda.Event on torch.cuda.ExternalStream(s) with
+        #  s = current_stream().cuda_stream: that wrapper of handle 0 is not ordered behind torch's current stream -- the side stream started
+        #  early in ~5 of 12 runs (stale upstream gradients); an event recorded on the torch.cuda.current_stream() OBJECT orders correctly,
+        #  12 of 12 (tools/ab_sigma_race.py, profiles/r06_sigma_concurrency.txt).  The engine is handed raw handles, so it orders raw handles.)
         L.check(L.load().ssdn_stream_order(C.c_void_p(s), C.c_void_p(side)))
         oplist.run(side)
         return side
