@@ -50,7 +50,7 @@ struct ChAux {                                            // a saved tensor an e
     ChPlane P;
     int where, pad_;
 };
-struct ChLoad { ssdn_view src; ChPlane P; int pad_; };
+struct ChLoad { ssdn_view src; ChPlane P; unsigned npc_magic; };   // (npc_magic: of P.C / 8, as ChLayer's)
 struct ChNext { const h16* w; int Ktot, npg, ts; };   // the next conv layer with an item for a wave: weights, row length, column groups, tap stride (w == NULL: none)
 struct ChLayer {
     int kind;
@@ -72,16 +72,31 @@ struct ChLayer {
     ChAux UM;
     ssdn_view upsum;
     int has_pd;                    // POOL_BWD: dz is also kept as a plane
-    int zero_off[2], zero_bytes[2], pad_;   // LDS ranges to clear before the layer writes its output planes (halo planes that reuse the space of dead ones)
+    int zero_off[2], zero_bytes[2];   // LDS ranges to clear before the layer writes its output planes (halo planes that reuse the space of dead ones)
+    int grp_next;                  // ch_grp of the layer behind this one (k_conv_chain runs one copy of the layer body per group)
 };
 struct ChainArgs {
     int N, nloads, nlayers, lds_bytes;
-    int ablate;                    // tuning aid (SSDN_CHAIN_ABLATE, -DSSDN_TUNING builds): 1 no MFMA loop, 2 no HBM stores, 4 no pool, 8 no weight stream
+    int grp0, pad0_;               // ch_grp of layer 0
+    int ablate;                    // tuning aid (SSDN_CHAIN_ABLATE, -DSSDN_TUNING builds): 1 no MFMA loop, 2 no HBM stores, 4 no pool, 8 no weight stream, 16 no L2 warm-up
     unsigned tap_dy, tap_dx;       // the nine tap offsets + 4, three bits each (SGPR constants: an s_load in the K loop would drain the LDS queue)
     int bf;                        // 0: forward (fp16, bias + LeakyReLU), 1: data gradients (bf16)
+    // L2 warm-up (k_conv_chain's first instructions): the 128-byte lines of every convolution's weights.  The weight stream runs one
+    // chunk ahead of the MFMAs -- 0.4 us at one column tile -- and in a training step its lines are in no L2 (Adam re-packed them a
+    // step ago, ~0.5 GB of traffic since): the workgroups of an XCD fetch a line each, once, while the arena is cleared and filled
+    const h16* pf_w[CH_MAX_LAYERS];
+    int pf_lines[CH_MAX_LAYERS];
     ChLoad ld[CH_MAX_LOADS];
     ChLayer ly[CH_MAX_LAYERS];
 };
+
+// Every pointer of this kernel comes out of the argument block in memory, so the compiler takes it for a generic one: FLAT loads and
+// stores, which count on BOTH vmcnt and lgkmcnt and return in no order it can rely on -- each wait behind one became vmcnt(0) lgkmcnt(0):
+// the K loop waited for the weight fragments it had just requested for the NEXT chunk at every chunk head and again at the LDS waits of
+// the first K-steps, and lds_barrier() waited for the stores to HBM.  Global accesses say so (address space 1): counted vmcnt waits.
+#define CH_G __attribute__((address_space(1)))
+template <typename T> static __device__ __forceinline__ T ch_ldg(const void* p) { return *(const CH_G T*)p; }
+template <typename T> static __device__ __forceinline__ void ch_stg(void* p, T v) { *(CH_G T*)p = v; }
 
 static __device__ __forceinline__ void lds_barrier() {   // this wave's LDS traffic done, then the workgroup barrier; global loads stay in flight
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -96,8 +111,11 @@ static __device__ __forceinline__ void chain_issue_w(half8 (&wr)[27], const h16*
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int ks = 0; ks < 3; ++ks) wr[t * 3 + ks] = ld_h8(lanep + (long long)t * tapstride + ks * 16);
+        for (int ks = 0; ks < 3; ++ks) wr[t * 3 + ks] = ch_ldg<half8>(lanep + (long long)t * tapstride + ks * 16);
 }
+
+template <int N> struct ch_ic { static constexpr int value = N; };
+static __host__ __device__ inline int ch_grp(int lhw) { return lhw > 7 ? 4 : lhw > 5 ? 2 : 1; }   // 32-pixel column tiles per work item
 
 template <bool BF>
 static __device__ __forceinline__ f32x16 ch_mma(half8 a, half8 b, f32x16 c) {
@@ -127,7 +145,7 @@ static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChHo
         for (int gq = 0; gq < 4; ++gq) {
             const int m0 = mt * 32 + gq * 8 + kh * 4;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) bb[gq][j] = L.bias[m0 < L.M ? m0 + j : 0];
+            for (int j = 0; j < 4; ++j) bb[gq][j] = ch_ldg<float>(L.bias + (m0 < L.M ? m0 + j : 0));
         }
     }
     int py[NPT], px[NPT];
@@ -144,6 +162,7 @@ static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChHo
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
     const int nch = L.Ktot / 48;
+    __builtin_assume(nch >= 1);
     const int tapstride = L.Mpad * L.Ktot;
     const h16* lanep = L.w + (long long)(mt * 32 + l31) * L.Ktot + kh * 8;
     for (int ch = 0; ch < nch && !CH_ABL(c, 1); ++ch) {
@@ -178,9 +197,11 @@ static __device__ __forceinline__ void chain_tile(const ChainArgs& c, const ChHo
 #pragma unroll
         for (int s = 0; s < 27; ++s) {
             const half8 a = wr[s];
-            if (!CH_ABL(c, 8)) wr[s] = ld_h8(np + (long long)(s / 3) * nts + (s % 3) * 16);
 #pragma unroll
             for (int p = 0; p < NPT; ++p) acc[p] = ch_mma<BF>(a, bq[s % BD][p], acc[p]);
+            // (behind the MFMAs that read the old fragment: its register takes the new one -- issued ahead of them, the 27 new fragments
+            //  land in registers of their own and are copied over, behind a vmcnt(0), at the end of every chunk)
+            if (!CH_ABL(c, 8)) wr[s] = ch_ldg<half8>(np + (long long)(s / 3) * nts + (s % 3) * 16);
             if (s + BD < 27) rd(s + BD, s % BD);
             __builtin_amdgcn_sched_barrier(0);                 // pin the step: left alone, the scheduler sinks every read to its MFMA
         }
@@ -227,7 +248,7 @@ static __device__ __forceinline__ unsigned ch_pk_positive(unsigned a) {     // 0
 // 16-byte piece cc of pixel q (row-major at the tensor's own resolution) of a saved tensor
 static __device__ __forceinline__ u32x4_t ch_aux(const ChAux& A, const char* smem, int n, int q, int cc) {
     if (A.where == 1) return *reinterpret_cast<const u32x4_t*>(smem + A.P.off + A.P.org + ((q >> A.P.lw) * A.P.roww + (q & ((1 << A.P.lw) - 1))) * A.P.str + cc * 16);
-    return *reinterpret_cast<const u32x4_t*>((const h16*)A.v.p + A.v.co + ((long long)(n << (A.P.lw + A.P.lh)) + q) * A.v.cs + cc * 8);
+    return ch_ldg<u32x4_t>((const h16*)A.v.p + A.v.co + ((long long)(n << (A.P.lw + A.P.lh)) + q) * A.v.cs + cc * 8);
 }
 
 // the same without a branch: BOTH an LDS read (address 0 of the arena when the tensor is not a plane) and a buffer load (out of range -- zeros,
@@ -274,21 +295,66 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
         const int f = first_from(0);
         if (f >= 0) chain_issue_w(wr, lanep_of(f, wave), c.ly[f].Mpad * c.ly[f].Ktot);
     }
+    // L2 warm-up: workgroup n runs on XCD n % 8; the (N + 7) / 8 workgroups of an XCD share the lines of each layer, two loads per thread
+    // and layer at most (buffer loads: a line past the end of a layer, or a table slot without one, moves nothing) -- no branches, all
+    // in flight together
+    unsigned pf = 0;
+#ifndef CH_NO_WARMUP
+    if (!CH_ABL(c, 16)) {
+        const int per = (c.N + 7) >> 3, ln0 = (n >> 3) + per * tid;
+#pragma unroll
+        for (int i = 0; i < CH_MAX_LAYERS; ++i) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(c.pf_w[i]), 0, c.pf_lines[i] << 7, SSDN_BUFFER_RSRC_FLAGS);
+#pragma unroll
+            for (int j = 0; j < 2; ++j) pf ^= __builtin_amdgcn_raw_buffer_load_b32(rs, (ln0 + j * per * CH_THREADS) << 7, 0, 0);
+        }
+#ifndef CH_NO_ARGWARM
+        // ... and the argument block itself: every layer starts with a batch of scalar loads from it, and a step's traffic away from
+        // the last launch its lines are in no L2 either (the scalar cache fills through the L2)
+        const __amdgpu_buffer_rsrc_t rs_c = __builtin_amdgcn_make_buffer_rsrc(const_cast<ChainArgs*>(cp), 0, (int)sizeof(ChainArgs), SSDN_BUFFER_RSRC_FLAGS);
+        pf ^= __builtin_amdgcn_raw_buffer_load_b32(rs_c, tid << 7, 0, 0);
+#endif
+    }
+#endif
+    stamp();
     for (int z = tid * 16; z < c.lds_bytes; z += CH_THREADS * 16) *reinterpret_cast<half8*>(smem + z) = zero_h8();
     lds_barrier();
+    stamp();
     for (int i = 0; i < c.nloads; ++i) {
         const ChPlane P = c.ld[i].P;
         const int npc = P.C >> 3, total = npc << (P.lw + P.lh);
+        const unsigned magic = c.ld[i].npc_magic;
         const h16* src = (const h16*)c.ld[i].src.p + c.ld[i].src.co;
-        for (int e = tid; e < total; e += CH_THREADS) {
-            const int q = e / npc, cc = e - q * npc;
-            const half8 v = ld_h8(src + ((long long)(n << (P.lw + P.lh)) + q) * c.ld[i].src.cs + cc * 8);
-            *reinterpret_cast<half8*>(smem + P.off + P.org + ((q >> P.lw) * P.roww + (q & ((1 << P.lw) - 1))) * P.str + cc * 16) = v;
+        // four entries of a thread in flight (one at a time, every entry was a round trip to HBM of its own: up to six in sequence per
+        // plane).  Measured and not kept: the first entries of EVERY plane requested ahead of the clearing loop through branch-free
+        // buffer loads over the whole table -- ~8 K cycles of address arithmetic on a lone wave per SIMD, more than the round trips saved
+        constexpr int LB = 4;
+        for (int e0 = tid; e0 < total; e0 += CH_THREADS * LB) {
+            half8 v[LB];
+            int lo[LB];
+#pragma unroll
+            for (int u = 0; u < LB; ++u) {
+                const int e = e0 + u * CH_THREADS;
+                const int ec = e < total ? e : e0;               // (past the end: a valid entry again, not written)
+                const int q = ch_div(ec, magic), cc = ec - q * npc;
+                v[u] = ch_ldg<half8>(src + ((long long)(n << (P.lw + P.lh)) + q) * c.ld[i].src.cs + cc * 8);
+                lo[u] = e < total ? P.off + P.org + ((q >> P.lw) * P.roww + (q & ((1 << P.lw) - 1))) * P.str + cc * 16 : -1;
+            }
+#pragma unroll
+            for (int u = 0; u < LB; ++u)
+                if (lo[u] >= 0) *reinterpret_cast<half8*>(smem + lo[u]) = v[u];
         }
     }
+    stamp();
+    asm volatile("" :: "v"(pf));                               // (the warm-up loads end here, with the arena's)
     lds_barrier();
     stamp();
-    for (int li = 0; li < nlayers; ++li) {
+    // One copy of the layer body per column-tile count (ch_grp: 4 / 2 / 1 tiles of 32 pixels per item), each run over the consecutive layers of
+    // its group.  With the three chain_tile forms as arms of one loop body the 27 weight fragments -- live from item to item, across
+    // layers -- sat in different registers in every arm: ~150 register copies on the way into and out of EVERY item (half as many cycles
+    // as the item's MFMAs at one column tile).  Now they change registers where the image size changes: a handful of times per launch.
+    auto layer = [&](const int li, auto nptc) __attribute__((always_inline)) -> int {
+        constexpr int NPT = decltype(nptc)::value;
         const ChLayer& L = c.ly[li];
         // ONE batch of scalar loads for everything up to the layer's last MFMA (the empty asm pins the values here: left alone, every field
         // is fetched where it is first used, behind a wait of its own)
@@ -297,8 +363,9 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
         H.P0 = L.P0; H.P1 = L.P1; H.PD = L.PD; H.tap_dy = tap_dy; H.tap_dx = tap_dx;
         int kind = L.kind, zb0 = L.zero_bytes[0], zb1 = L.zero_bytes[1], zo0 = L.zero_off[0], zo1 = L.zero_off[1];
         ChNext NX = L.nx[wave];
+        int grp_next = L.grp_next;
         asm volatile("" : "+s"(H.M), "+s"(H.Mpad), "+s"(H.Ktot), "+s"(H.c0), "+s"(H.up0), "+s"(H.w), "+s"(H.bias), "+s"(kind), "+s"(zb0), "+s"(zb1),
-                     "+s"(zo0), "+s"(zo1), "+s"(NX.w), "+s"(NX.Ktot), "+s"(NX.npg), "+s"(NX.ts));
+                     "+s"(zo0), "+s"(zo1), "+s"(NX.w), "+s"(NX.Ktot), "+s"(NX.npg), "+s"(NX.ts), "+s"(grp_next));
         asm volatile("" : "+s"(H.P0.off), "+s"(H.P0.str), "+s"(H.P0.roww), "+s"(H.P0.org), "+s"(H.P1.off), "+s"(H.P1.str), "+s"(H.P1.roww), "+s"(H.P1.org),
                      "+s"(H.PD.off), "+s"(H.PD.str), "+s"(H.PD.roww), "+s"(H.PD.org), "+s"(H.PD.lw), "+s"(H.PD.lh));
         const ChPlane PD = H.PD;
@@ -310,7 +377,8 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
             lds_barrier();
         }
         if (kind == CH_CONV) {
-            const int npg = lhw > 7 ? 2 : 1, nitems = (H.Mpad >> 5) * npg;
+            constexpr int npg = NPT == 4 ? 2 : 1;
+            const int nitems = (H.Mpad >> 5) * npg;
             for (int it = wave; it < nitems; it += 4) {
                 const int nit = it + 4;
                 // the weight stream's next stop: this wave's next item of the layer, else its first item of the next layer that has one
@@ -321,9 +389,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                 else if (NX.w) { nlp = NX.w + (long long)((wave / NX.npg) * 32 + l31) * NX.Ktot + kh * 8; nts = NX.ts; }
                 else { nlp = H.w + (long long)((it / npg) * 32 + l31) * H.Ktot + kh * 8 + (H.Ktot - 48); nts = H.Mpad * H.Ktot; }
                 const int mt = it / npg, pg = it - mt * npg;
-                if (lhw > 7) chain_tile<4, BF>(c, H, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
-                else if (lhw > 5) chain_tile<2, BF>(c, H, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
-                else chain_tile<1, BF>(c, H, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
+                chain_tile<NPT, BF>(c, H, smem, mt, pg, l31, kh, wr, nlp, nts, stamp);
             }                                                  // (an idle wave keeps the chunk it holds for its next layer)
             stamp();
             lds_barrier();
@@ -333,7 +399,50 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                 const int total = npc << lhw;
                 h16* dst = (h16*)L.dst.p + L.dst.co;
                 const bool fix = BF && (L.AD.where || L.MK.where);
-                for (int e = tid; e < total; e += CH_THREADS) {
+                const bool far = fix && (L.AD.where == 2 || L.MK.where == 2);
+                if constexpr (BF) {
+                    if (far) {
+                        // a saved tensor in HBM (images of more than 64 pixels): the pieces of three entries in flight together, fetched
+                        // without a branch (ch_aux_nb) -- one entry at a time, each was a round trip to HBM in sequence, six per thread in
+                        // the 16x16 layer (10.3 K -> 8.9 K cycles).  Saved tensors that are LDS planes keep the plain loop below: there
+                        // the branch-free fetch's idle buffer load is the longer wait (measured: +40 %)
+                        const __amdgpu_buffer_rsrc_t rs_ad = ch_aux_rsrc(L.AD), rs_mk = ch_aux_rsrc(L.MK);
+                        const bool has_ad = L.AD.where != 0, has_mk = L.MK.where != 0;
+                        constexpr int SB = 3;
+                        for (int e0 = tid; e0 < total; e0 += CH_THREADS * SB) {
+                            u32x4_t ab[SB], mb[SB];
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const int e = e0 + u * CH_THREADS < total ? e0 + u * CH_THREADS : e0;
+                                const int q = ch_div(e, L.npc_magic), cc = e - q * npc;
+                                ab[u] = ch_aux_nb(L.AD, rs_ad, smem, n, q, cc);
+                                mb[u] = ch_aux_nb(L.MK, rs_mk, smem, n, q, cc);
+                            }
+#pragma unroll
+                            for (int u = 0; u < SB; ++u) {
+                                const int e = e0 + u * CH_THREADS;
+                                if (e >= total) break;
+                                const int q = ch_div(e, L.npc_magic), cc = e - q * npc;
+                                char* pp = ch_px(smem, PD, q >> PD.lw, q & ((1 << PD.lw) - 1)) + cc * 16;
+                                u32x4_t o = *reinterpret_cast<const u32x4_t*>(pp);
+#pragma unroll
+                                for (int w = 0; w < 4; ++w) {
+                                    float v0 = bf_lo(o[w]) + (has_ad ? bf_lo(ab[u][w]) : 0.f);
+                                    float v1 = bf_hi(o[w]) + (has_ad ? bf_hi(ab[u][w]) : 0.f);
+                                    if (has_mk) {
+                                        v0 *= lrelu_grad(f16_lo(mb[u][w]));
+                                        v1 *= lrelu_grad(f16_hi(mb[u][w]));
+                                    }
+                                    o[w] = pack_bf16x2(v0, v1);
+                                }
+                                *reinterpret_cast<u32x4_t*>(pp) = o;
+                                if (cc * 8 >= L.dst_c0 && L.dst.p && !CH_ABL(c, 2))
+                                    ch_stg<u32x4_t>(dst + ((long long)(n << lhw) + q) * L.dst.cs + cc * 8, o);
+                            }
+                        }
+                    }
+                }
+                for (int e = tid; e < total && !far; e += CH_THREADS) {
                     const int q = ch_div(e, L.npc_magic), cc = e - q * npc;
                     char* pp = ch_px(smem, PD, q >> PD.lw, q & ((1 << PD.lw) - 1)) + cc * 16;
                     u32x4_t o = *reinterpret_cast<const u32x4_t*>(pp);
@@ -356,7 +465,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                         }
                     }
                     if (cc * 8 >= L.dst_c0 && L.dst.p && !CH_ABL(c, 2))
-                        *reinterpret_cast<u32x4_t*>(dst + ((long long)(n << lhw) + q) * L.dst.cs + cc * 8) = o;
+                        ch_stg<u32x4_t>(dst + ((long long)(n << lhw) + q) * L.dst.cs + cc * 8, o);
                 }
             }
             stamp();
@@ -383,7 +492,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                         for (int q = 0; q < 4; ++q)
                             r[q] = pack_bf16x2(sum[2 * q] * lrelu_grad(f16_lo(um[q])), sum[2 * q + 1] * lrelu_grad(f16_hi(um[q])));
                         *reinterpret_cast<u32x4_t*>(ch_px(smem, PU, pi, pj) + cc * 16) = r;
-                        if (!CH_ABL(c, 2)) *reinterpret_cast<u32x4_t*>(dst + ((long long)(n << (lhw - 2)) + pq) * L.upsum.cs + cc * 8) = r;
+                        if (!CH_ABL(c, 2)) ch_stg<u32x4_t>(dst + ((long long)(n << (lhw - 2)) + pq) * L.upsum.cs + cc * 8, r);
                     }
                     wrote = true;
                 }
@@ -414,7 +523,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                             }
                         }
                         *reinterpret_cast<u32x4_t*>(ch_px(smem, PP, pi, pj) + cc * 16) = best;
-                        if (!CH_ABL(c, 2)) *reinterpret_cast<u32x4_t*>(dst + ((long long)(n << (lhw - 2)) + pq) * L.pool.cs + cc * 8) = best;
+                        if (!CH_ABL(c, 2)) ch_stg<u32x4_t>(dst + ((long long)(n << (lhw - 2)) + pq) * L.pool.cs + cc * 8, best);
                     }
                     wrote = true;
                 }
@@ -492,7 +601,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                     if (y < 0) continue;
                     const int x = 2 * j + (k & 1);
                     if (L.has_pd) *reinterpret_cast<u32x4_t*>(ch_px(smem, PD, y, x) + cc * 16) = o[k];
-                    if (!CH_ABL(c, 2)) *reinterpret_cast<u32x4_t*>(dz + ((long long)(n << lhwf) + (y << lw) + x) * L.dst.cs + cc * 8) = o[k];
+                    if (!CH_ABL(c, 2)) ch_stg<u32x4_t>(dz + ((long long)(n << lhwf) + (y << lw) + x) * L.dst.cs + cc * 8, o[k]);
                 }
                 if (L.pool_shifted && i == Ho - 1) {            // shifted pooling never looks at the last row: its gradient is zero
                     const u16x8 z = zero_b8();
@@ -500,7 +609,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
                     for (int dc = 0; dc < 2; ++dc) {
                         const int x = 2 * j + dc;
                         if (L.has_pd) *reinterpret_cast<u16x8*>(ch_px(smem, PD, H - 1, x) + cc * 16) = z;
-                        if (!CH_ABL(c, 2)) st_b8(dz + ((long long)(n << lhwf) + ((H - 1) << lw) + x) * L.dst.cs + cc * 8, z);
+                        if (!CH_ABL(c, 2)) ch_stg<u16x8>(dz + ((long long)(n << lhwf) + ((H - 1) << lw) + x) * L.dst.cs + cc * 8, z);
                     }
                 }
               }
@@ -508,6 +617,13 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
             if (L.has_pd) lds_barrier();
             stamp();
         }
+        return grp_next;
+    };
+    int li = 0, g = c.grp0;
+    while (li < nlayers) {
+        if (g == 4) do g = layer(li++, ch_ic<4>{}); while (li < nlayers && g == 4);
+        else if (g == 2) do g = layer(li++, ch_ic<2>{}); while (li < nlayers && g == 2);
+        else do g = layer(li++, ch_ic<1>{}); while (li < nlayers && g == 1);
     }
 }
 
@@ -754,6 +870,8 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
         ChLoad& Ld = out->ld[out->nloads++];
         Ld.src = b.planes[i].v;
         Ld.P = desc(PlaneRef{i, 0});
+        const unsigned lnpc = (unsigned)Ld.P.C / 8;
+        Ld.npc_magic = lnpc <= 1 ? 0u : (unsigned)((0x100000000ull + lnpc - 1) / lnpc);
     }
     for (int i = 0; i < n; ++i) {
         const LayerRec& R = b.layers[i];
@@ -784,6 +902,24 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
         for (size_t r = 0; r < zero[i].size(); ++r) { L.zero_off[r] = zero[i][r].first; L.zero_bytes[r] = zero[i][r].second; }
         const unsigned npc = (unsigned)L.M / 8;
         L.npc_magic = npc <= 1 ? 0u : (unsigned)((0x100000000ull + npc - 1) / npc);
+    }
+    // the layer body a layer runs in (k_conv_chain): by its image size; a POOL_BWD layer stays in the body of the convolution behind it
+    // (or, behind the last convolution, of the one before it)
+    {
+        int grp[CH_MAX_LAYERS], g = 0;
+        for (int i = n - 1; i >= 0; --i) {
+            if (out->ly[i].kind == CH_CONV) g = ch_grp(out->ly[i].PD.lw + out->ly[i].PD.lh);
+            grp[i] = g;
+        }
+        for (int i = 0; i < n; ++i)
+            if (!grp[i]) grp[i] = i ? grp[i - 1] : 1;
+        out->grp0 = grp[0];
+        for (int i = 0; i < n; ++i)
+            if (out->ly[i].kind == CH_CONV) {
+                out->pf_w[i] = out->ly[i].w;
+                out->pf_lines[i] = (int)(((long long)9 * out->ly[i].Mpad * out->ly[i].Ktot * 2) >> 7);
+            }
+        for (int i = 0; i < n; ++i) out->ly[i].grp_next = grp[i + 1 < n ? i + 1 : i];
     }
     // the weight stream's next stop behind each layer, per wave: the first later convolution that has an item for the wave
     for (int i = 0; i < n; ++i)

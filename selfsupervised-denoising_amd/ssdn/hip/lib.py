@@ -237,6 +237,8 @@ def load() -> C.CDLL:
     lib.ssdn_train_step.restype = C.c_int
     if lib.ssdn_abi_version() != ABI_VERSION:
         raise SsdnHipError("libssdn_hip.so ABI version mismatch")
+    if os.environ.get("SSDN_CHAIN_MODE"):        # A/B aid (tools/): ssdn_conv_set_chain before any plan is made -- 0 off, 1 default, 2 see conv_chain.hip
+        lib.ssdn_conv_set_chain(int(os.environ["SSDN_CHAIN_MODE"]))
     _lib = lib
     return lib
 

@@ -78,16 +78,24 @@ if os.environ.get("SSDN_LIB"):
     t = tr.cpu().view(N, 96)
     nst = int((t[0] != 0).sum())
     d = (t[:, 1:nst] - t[:, :nst - 1]).double()
-    names = ["start: zero, load, barriers"]
+    # the stamps of wave 0 (csrc/conv_chain.hip): a convolution -- per work item of the wave (items wave, wave + 4, ..) and 48-channel chunk
+    # one after the B-fragment pipeline is filled and one after the 27 K-steps, then four behind the items; a POOL_BWD op -- one
+    names = ["start: first weights + warm-up requested", "start: arena cleared, barrier", "start: planes loaded", "start: warm-up arrived, barrier"]
     for i in range(best):
-        nch = ol.args[i].Ktot // 48 if hasattr(ol.args[i], "Ktot") else 0
-        names += sum([["L%d chunk %d prologue" % (i, k), "L%d chunk %d 27 K-steps" % (i, k)] for k in range(nch)], [])
-        names += ["L%d epilogue" % i, "L%d barrier" % i, "L%d store" % i, "L%d pool" % i]
+        ar = ol.args[i]
+        if not hasattr(ar, "Ktot"):
+            names += ["L%d pool_bwd" % i]
+            continue
+        nch = ar.Ktot // 48
+        nitems = (ar.Mpad // 32) * (2 if ar.H * ar.W > 128 else 1)
+        for it in range((nitems + 3) // 4):
+            names += sum([["L%d item %d chunk %d: way to the first MFMA" % (i, it, k), "L%d item %d chunk %d: 27 K-steps" % (i, it, k)] for k in range(nch)], [])
+        names += ["L%d epilogue of the last item" % i, "L%d barrier" % i, "L%d second pass + store" % i, "L%d pool / upsum" % i]
     for i in range(best):
         ar = ol.args[i]
         print("  op %2d %-10s %s" % (i, next(k for k, v in L.OP.items() if v == full.arr[at + i].type),
               " ".join("%s=%s" % (f, getattr(ar, f)) for f in ("N", "H", "W", "Ktot", "M", "Mpad", "ntaps", "shifted") if hasattr(ar, f))))
     print("stamps per workgroup: %d; s_memtime ticks (mean over workgroups, min, max):" % nst)
     for i in range(nst - 1):
-        print("  %-28s %8.1f %6d %6d" % (names[i] if i < len(names) else "?", float(d[:, i].mean()), int(d[:, i].min()), int(d[:, i].max())))
+        print("  %-44s %8.1f %6d %6d" % (names[i] if i < len(names) else "?", float(d[:, i].mean()), int(d[:, i].min()), int(d[:, i].max())))
     print("  total %.1f ticks" % float((t[:, nst - 1] - t[:, 0]).double().mean()))
