@@ -81,6 +81,7 @@ struct ChainArgs {
     int ablate;                    // tuning aid (SSDN_CHAIN_ABLATE, -DSSDN_TUNING builds): 1 no MFMA loop, 2 no HBM stores, 4 no pool, 8 no weight stream, 16 no L2 warm-up
     unsigned tap_dy, tap_dx;       // the nine tap offsets + 4, three bits each (SGPR constants: an s_load in the K loop would drain the LDS queue)
     int bf;                        // 0: forward (fp16, bias + LeakyReLU), 1: data gradients (bf16)
+    ChNext first[4];               // per wave: the first convolution with an item for it (what the kernel's entry used to find by walking ly[])
     // L2 warm-up (k_conv_chain's first instructions): the 128-byte lines of every convolution's weights.  The weight stream runs one
     // chunk ahead of the MFMAs -- 0.4 us at one column tile -- and in a training step its lines are in no L2 (Adam re-packed them a
     // step ago, ~0.5 GB of traffic since): the workgroups of an XCD fetch a line each, once, while the arena is cleared and filled
@@ -279,32 +280,33 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
 #endif
     };
     stamp();
-    const int nlayers = c.nlayers;
-    const unsigned tap_dy = c.tap_dy, tap_dx = c.tap_dx;
-    // the wave's work items in order: item it = wave, wave + 4, .. of every conv layer; item -> (32-row tile it / npg, group it % npg
-    // of up to four 32-pixel column tiles; npg = 2 for 256-pixel images, else 1)
-    auto npg_of = [&](int li) { return c.ly[li].PD.lw + c.ly[li].PD.lh > 7 ? 2 : 1; };
-    auto items_of = [&](int li) { return (c.ly[li].Mpad >> 5) * npg_of(li); };
-    auto lanep_of = [&](int li, int it) { return c.ly[li].w + (long long)((it / npg_of(li)) * 32 + l31) * c.ly[li].Ktot + kh * 8; };
-    auto first_from = [&](int li) {                            // first conv layer >= li with an item for this wave, or -1
-        while (li < nlayers && !(c.ly[li].kind == CH_CONV && wave < items_of(li))) ++li;
-        return li < nlayers ? li : -1;
-    };
+    // everything the kernel's entry needs sits at the head of the argument block and is fetched as ONE batch of scalar loads (pinned by the
+    // empty asm): a launch finds none of these lines in its L2 (~2 K cycles per round trip), and field by field -- the layer count, the
+    // walk to the wave's first convolution, its weights' address, the tables of the warm-up -- they were seven round trips in sequence
+    int nlayers = c.nlayers, nloads = c.nloads, lds_bytes = c.lds_bytes, grp0 = c.grp0, nimg = c.N;
+    unsigned tap_dy = c.tap_dy, tap_dx = c.tap_dx;
+    ChNext F = c.first[wave];
+    const h16* pfw[CH_MAX_LAYERS];
+    int pfl[CH_MAX_LAYERS];
+#pragma unroll
+    for (int i = 0; i < CH_MAX_LAYERS; ++i) { pfw[i] = c.pf_w[i]; pfl[i] = c.pf_lines[i]; }
+    static_assert(CH_MAX_LAYERS == 12, "the pins below name every table slot");
+    asm volatile("" : "+s"(nlayers), "+s"(nloads), "+s"(lds_bytes), "+s"(grp0), "+s"(nimg), "+s"(tap_dy), "+s"(tap_dx), "+s"(F.w), "+s"(F.Ktot),
+                 "+s"(F.npg), "+s"(F.ts), "+s"(pfl[0]), "+s"(pfl[1]), "+s"(pfl[2]), "+s"(pfl[3]), "+s"(pfl[4]), "+s"(pfl[5]), "+s"(pfl[6]),
+                 "+s"(pfl[7]), "+s"(pfl[8]), "+s"(pfl[9]), "+s"(pfl[10]), "+s"(pfl[11]), "+s"(pfw[0]), "+s"(pfw[1]), "+s"(pfw[2]));
+    asm volatile("" : "+s"(pfw[3]), "+s"(pfw[4]), "+s"(pfw[5]), "+s"(pfw[6]), "+s"(pfw[7]), "+s"(pfw[8]), "+s"(pfw[9]), "+s"(pfw[10]), "+s"(pfw[11]));
     half8 wr[27];
-    {
-        const int f = first_from(0);
-        if (f >= 0) chain_issue_w(wr, lanep_of(f, wave), c.ly[f].Mpad * c.ly[f].Ktot);
-    }
+    if (F.w) chain_issue_w(wr, F.w + (long long)((wave / F.npg) * 32 + l31) * F.Ktot + kh * 8, F.ts);
     // L2 warm-up: workgroup n runs on XCD n % 8; the (N + 7) / 8 workgroups of an XCD share the lines of each layer, two loads per thread
     // and layer at most (buffer loads: a line past the end of a layer, or a table slot without one, moves nothing) -- no branches, all
     // in flight together
     unsigned pf = 0;
 #ifndef CH_NO_WARMUP
     if (!CH_ABL(c, 16)) {
-        const int per = (c.N + 7) >> 3, ln0 = (n >> 3) + per * tid;
+        const int per = (nimg + 7) >> 3, ln0 = (n >> 3) + per * tid;
 #pragma unroll
         for (int i = 0; i < CH_MAX_LAYERS; ++i) {
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(c.pf_w[i]), 0, c.pf_lines[i] << 7, SSDN_BUFFER_RSRC_FLAGS);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<h16*>(pfw[i]), 0, pfl[i] << 7, SSDN_BUFFER_RSRC_FLAGS);
 #pragma unroll
             for (int j = 0; j < 2; ++j) pf ^= __builtin_amdgcn_raw_buffer_load_b32(rs, (ln0 + j * per * CH_THREADS) << 7, 0, 0);
         }
@@ -317,17 +319,18 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
     }
 #endif
     stamp();
-    for (int z = tid * 16; z < c.lds_bytes; z += CH_THREADS * 16) *reinterpret_cast<half8*>(smem + z) = zero_h8();
+    for (int z = tid * 16; z < lds_bytes; z += CH_THREADS * 16) *reinterpret_cast<half8*>(smem + z) = zero_h8();
     lds_barrier();
     stamp();
-    for (int i = 0; i < c.nloads; ++i) {
+    for (int i = 0; i < nloads; ++i) {
         const ChPlane P = c.ld[i].P;
         const int npc = P.C >> 3, total = npc << (P.lw + P.lh);
         const unsigned magic = c.ld[i].npc_magic;
         const h16* src = (const h16*)c.ld[i].src.p + c.ld[i].src.co;
         // four entries of a thread in flight (one at a time, every entry was a round trip to HBM of its own: up to six in sequence per
         // plane).  Measured and not kept: the first entries of EVERY plane requested ahead of the clearing loop through branch-free
-        // buffer loads over the whole table -- ~8 K cycles of address arithmetic on a lone wave per SIMD, more than the round trips saved
+        // buffer loads over the whole table (~8 K cycles of address arithmetic on a lone wave per SIMD, more than the round trips
+        // saved), and four planes at a time (backward chain -1 us, forward chain -- one plane -- +2.5 us in the step)
         constexpr int LB = 4;
         for (int e0 = tid; e0 < total; e0 += CH_THREADS * LB) {
             half8 v[LB];
@@ -619,7 +622,7 @@ __global__ __launch_bounds__(CH_THREADS) void k_conv_chain(const ChainArgs* __re
         }
         return grp_next;
     };
-    int li = 0, g = c.grp0;
+    int li = 0, g = grp0;
     while (li < nlayers) {
         if (g == 4) do g = layer(li++, ch_ic<4>{}); while (li < nlayers && g == 4);
         else if (g == 2) do g = layer(li++, ch_ic<2>{}); while (li < nlayers && g == 2);
@@ -920,6 +923,14 @@ static bool chain_build(const ssdn_op* items, int n, ChainArgs* out) {
                 out->pf_lines[i] = (int)(((long long)9 * out->ly[i].Mpad * out->ly[i].Ktot * 2) >> 7);
             }
         for (int i = 0; i < n; ++i) out->ly[i].grp_next = grp[i + 1 < n ? i + 1 : i];
+    }
+    for (int w = 0; w < 4; ++w) {
+        out->first[w] = ChNext{nullptr, 0, 1, 0};
+        for (int j = 0; j < n; ++j) {
+            const ChLayer& J = out->ly[j];
+            const int npg = J.PD.lw + J.PD.lh > 7 ? 2 : 1;
+            if (J.kind == CH_CONV && w < (J.Mpad >> 5) * npg) { out->first[w] = ChNext{J.w, J.Ktot, npg, J.Mpad * J.Ktot}; break; }
+        }
     }
     // the weight stream's next stop behind each layer, per wave: the first later convolution that has an item for the wave
     for (int i = 0; i < n; ++i)
