@@ -62,6 +62,9 @@
 #ifndef CD_MOVE_BARRIER
 #define CD_MOVE_BARRIER 1
 #endif
+#ifndef CD_WARMUP
+#define CD_WARMUP 1
+#endif
 
 namespace {
 
@@ -205,6 +208,14 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
         it_first = blockIdx.x; it_stride = G_; it_end = x.nitems;
     }
     if (it_first >= it_end) return;
+#if CD_WARMUP
+    // L2 warm-up: a launch finds its weights in no L2, and all workgroups of an XCD walk them in the same order at the same time -- every
+    // slice of the first tile is a miss for all of them, a step ahead of its use.  The workgroups of the XCD (blockIdx % 8) fetch one
+    // 128-byte line per thread, all lines of the chunk-major copy, before anything else
+    const int pf_line = (blockIdx.x >> 3) * 256 + tid;
+    const unsigned pf = __builtin_amdgcn_raw_buffer_load_b32(
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.wc), 0, 9 * a.Mpad * a.Ktot * 2, SSDN_BUFFER_RSRC_FLAGS), pf_line << 7, 0, 0);
+#endif
 
     // ---- per-lane constants ---------------------------------------------------------------------------------------------
     // (few on purpose: with two fragment sets and 96 accumulator registers the allocator has ~40 registers for everything else; what the
@@ -904,6 +915,9 @@ __global__ __launch_bounds__(256, 2) void k_cdma(ssdn_conv_args a, CdAux x) {
     }
     };
     if (wload) run(cd_ic<1>{}); else run(cd_ic<0>{});
+#if CD_WARMUP
+    asm volatile("" :: "v"(pf));
+#endif
 }
 
 #ifndef CD_KERNEL_ONLY      // (tuning aid: a translation unit that includes this file to compile single instantiations)
