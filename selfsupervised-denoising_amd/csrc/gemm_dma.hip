@@ -53,6 +53,9 @@ __device__ __forceinline__ f32x16 gd_mma(half8 av, half8 bv, f32x16 c) {
         return __builtin_amdgcn_mfma_f32_32x32x16_f16(av, bv, c, 0, 0, 0);
 }
 
+#ifndef GD_WARMUP
+#define GD_WARMUP 1
+#endif
 #ifndef GD_DA_V
 #define GD_DA_V 3
 #define GD_DB_V 3
@@ -106,6 +109,13 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
     const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(a.src0.p, 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_dst = __builtin_amdgcn_make_buffer_rsrc(a.dst.p, 0, GD_ABL(x, 2) ? 0 : (int)0x80000000, SSDN_BUFFER_RSRC_FLAGS);
+#if GD_WARMUP
+    // L2 warm-up (as k_cdma's): the weight matrix streams from L2 chunk by chunk, in the same order in every workgroup -- and a launch
+    // finds it in no L2.  One 128-byte line per thread, the workgroups of an XCD (blockIdx % 8) share the matrix
+    const unsigned pf = __builtin_amdgcn_raw_buffer_load_b32(
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, a.Mpad * a.Ktot * 2, SSDN_BUFFER_RSRC_FLAGS),
+        (int)((blockIdx.x >> 3) * (64 * NW) + tid) << 7, 0, 0);
+#endif
     const __amdgpu_buffer_rsrc_t rs_mask = __builtin_amdgcn_make_buffer_rsrc(a.mask.p, 0, (EPI & 1) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_ur = __builtin_amdgcn_make_buffer_rsrc(a.unrot.p, 0, UNROT && !GD_ABL(x, 2) ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
     const __amdgpu_buffer_rsrc_t rs_um = __builtin_amdgcn_make_buffer_rsrc(a.unrot_mask.p, 0, UNROT ? (int)0x80000000 : 0, SSDN_BUFFER_RSRC_FLAGS);
@@ -377,6 +387,9 @@ __global__ __launch_bounds__(64 * NWP * NWM, 1) void k_gdma(ssdn_conv_args a, Gd
             }
         }
     }
+#if GD_WARMUP
+    asm volatile("" :: "v"(pf));
+#endif
 }
 
 // ---- host ----------------------------------------------------------------------------------------------------------------------
