@@ -22,6 +22,18 @@
 //     the plane applies what the separate launches apply to their transposed tile (skip-gradient add, LeakyReLU' mask -- in place),
 //     stores 16-byte pieces to HBM (every tensor is still written: the weight gradients and the layers outside the run read them),
 //     and derives the fused outputs (Shift2d + MaxPool2d; the 2x2 sums of the up-sampled half) into their own planes.
+// Round 6 -- what a lone wave per SIMD pays for, found in the disassembly and in the step's kernel trace (forward chain 61.7 -> 47.8 us,
+// backward chain 104.5 -> 94.5 us in the training step; results unchanged bit for bit):
+//   * every pointer comes out of the argument block, so the compiler took the accesses for FLAT ones (vmcnt AND lgkmcnt, no order it
+//     can count on): each wait behind one was vmcnt(0) lgkmcnt(0) -- the K loop waited at every chunk head for the weight fragments
+//     it had just requested for the NEXT chunk.  Global accesses now (address space 1): counted waits;
+//   * the three chain_tile forms (4 / 2 / 1 column tiles) were arms of one loop body and the 27 weight fragments changed registers
+//     on the way into and out of every work item (~150 copies): one copy of the layer body per form now (k_conv_chain);
+//   * a launch finds neither its weights nor its argument block in any L2 (a step's traffic lies between two launches), and the weight
+//     stream runs one chunk ahead only: the workgroups of an XCD fetch a 128-byte line each of both at kernel entry;
+//   * the K loop itself is bound by the L1 path at one or two column tiles: a wave's weight fragment (1 KiB per K-step, rows 96..288 B
+//     apart) is used for ONE MFMA per column tile, four waves x 1 KiB per 32 cycles = 128 B/clk against 64 -- measured 67 / 107 / 200
+//     cycles per K-step at 1 / 2 / 4 column tiles (MFMA: 32 / 64 / 128).
 // Results are BIT-IDENTICAL to the separate launches: every output element accumulates chunk -> tap -> K-step in the same order with
 // the same MFMA instruction and k-slot assignment as k_conv's flat path, and the epilogue arithmetic is applied to the same rounded
 // values in the same order (tests/test_hip_ops.py::test_conv_chain_is_bit_identical, ::test_backward_chain_is_bit_identical).
