@@ -155,11 +155,12 @@ def test_bench_two_ranks_on_one_gpu_over_gloo():
         assert p.returncode != 0 and len(lines) == 1 and "error" in json.loads(lines[0]), p.stdout[-2000:]
 
 
-def _rccl_world1(port, q):
+def _rccl_world1(port, q, plan="split"):
     """(own process: the process group must not outlive the test, and RCCL initialises once per process)"""
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     import torch.distributed as dist
-    from ssdn.hip import dp
+    from ssdn.hip import dp, graph
+    graph.WGRAD_MEGA = plan                             # (what bench.py's SSDN_DP_PLAN sets: the weight-gradient plan of the engines built below)
     try:
         torch.cuda.set_device(0)
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
@@ -185,7 +186,10 @@ def _rccl_world1(port, q):
         torch.cuda.synchronize()
         # when did the buckets complete?  (marks carry timestamps in this test): the head bucket's only mark vs the final one
         early = 1e3 * ex.events[ex.waits[0][0]].elapsed_time(ex.events[ex.waits[1][-1]])
-        info = {"groups": ex.groups, "waits": {k: list(v) for k, v in ex.waits.items()}, "head_mark_to_final_mark_us": early}
+        final = ex.events[ex.waits[max(ex.waits)][-1]] if plan != "split" else ex.events[ex.waits[1][-1]]
+        lead = [1e3 * ex.events[ex.waits[g[-1]][-1]].elapsed_time(final) for g in ex.groups if g[-1] in ex.waits]
+        info = {"groups": ex.groups, "waits": {k: list(v) for k, v in ex.waits.items()}, "head_mark_to_final_mark_us": early,
+                "group_mark_to_final_mark_us": lead}
         dist.destroy_process_group()
         # (buckets whose completion marks coincide -- all of the main net's with the chip-wide weight-gradient launch -- are ONE collective)
         q.put(("ok", plain, got, seen, ex.comm_stream.cuda_stream, [hi - lo for lo, hi, _ in ex._units()], info))
@@ -222,3 +226,24 @@ def test_rccl_exchange_world_one_is_bit_identical():
     #  batch 4 here measured ~100 us, ~0.4 ms at the benchmark batch)
     assert info["head_mark_to_final_mark_us"] > 0.0, info
     print("head mark -> final mark: %.1f us" % info["head_mark_to_final_mark_us"])
+
+
+def test_rccl_exchange_buckets_plan_overlaps_collectives():
+    """with the weight-gradient plan "buckets" (bench.py: SSDN_DP_PLAN=buckets) every gradient bucket of the main
+    network is its own collective, enqueued on the communication stream behind the bucket's own completion mark -- at least two of them fire
+    while the backward pass still has later buckets' launches in front of it.  Same weights as the run without an exchange, bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_rccl_world1, args=(_free_port(), q, "buckets"))
+    p.start()
+    tag, plain, got, seen, comm, sizes, info = q.get(timeout=600)
+    p.join(timeout=120)
+    assert tag == "ok", plain
+    assert np.array_equal(plain, got)
+    assert len(seen) == 3 * len(sizes) and all(a for _, a, _ in seen) and all(s == comm for _, _, s in seen)
+    main = [g for g in info["groups"] if g and g[-1] <= 3]
+    assert len(main) >= 3, info                        # head | dec1 | dec2..5 | encoder: no two of them complete together
+    early = [us for us in info["group_mark_to_final_mark_us"] if us > 0.0]
+    assert len(early) >= 2, info                       # >= 2 collectives are released before the backward pass's last mark fires
+    print("bucket marks ahead of the final mark (us):", ["%.1f" % us for us in info["group_mark_to_final_mark_us"]])
+
